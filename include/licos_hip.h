@@ -1,0 +1,155 @@
+/*
+ * licos_hip.h - C ABI of the MI355X (gfx950) implementation of the LICOS
+ * learned-image-compression hot path.
+ *
+ * This is the drop-in boundary.  The reference reaches the same
+ * work through CompressAI's torch modules and its two pybind11 extensions;
+ * each entry point below names the reference interface it replaces
+ * (paths under /root/reference, or the upstream CompressAI file when the code
+ * lives in that un-vendored dependency).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative LICOS_E* code otherwise;
+ *     licos_last_error() returns a thread-local message for the last failure;
+ *   - no exceptions cross the boundary, no ownership is transferred: every
+ *     buffer is caller-owned (device pointers unless the name says host);
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the
+ *     library never synchronises the device;
+ *   - activations of the 32-bit path are NCHW fp32 exactly like torch; the
+ *     16-bit MFMA path keeps activations in the blocked layout
+ *     [B][C/16][H][W][16] fp16 ("blk16") between stages.
+ */
+#ifndef LICOS_HIP_H
+#define LICOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LICOS_OK 0
+#define LICOS_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define LICOS_EHIP (-2)     /* HIP runtime error (message has the detail)  */
+#define LICOS_EDOMAIN (-3)  /* invalid pmf, see licos_pmf_to_quantized_cdf */
+#define LICOS_EOVERFLOW (-4)
+
+#define LICOS_ABI_VERSION 1
+
+typedef struct licos_device_props {
+  int compute_units;
+  int wavefront_size;
+  int lds_bytes_per_cu;
+  int clock_khz;
+  size_t hbm_bytes;
+  char arch[32]; /* e.g. "gfx950" */
+} licos_device_props;
+
+const char *licos_last_error(void);
+int licos_abi_version(void);
+/* device discovery (replaces torch.cuda.is_available()/device choice, licos/train.py:74) */
+int licos_query(int device, licos_device_props *out);
+
+/* ---------------------------------------------------------------- host side
+ * CompressAI cpp_exts/ops/ops.cpp pmf_to_quantized_cdf, called from
+ * EntropyBottleneck.update() <- /root/reference/eval_script.py:72,88.
+ * cdf_out has n+1 entries.  LICOS_EDOMAIN on negative/non-finite/all-zero pmf. */
+int licos_pmf_to_quantized_cdf(const float *pmf_host, int n, int precision, int32_t *cdf_out_host);
+
+/* Encoder-side table derived from the integer CDFs: per (row, symbol) a 16-byte
+ * record {rcp_freq:u64, bias:u32, freq:u16|rcp_shift:u16} implementing the
+ * exact x/freq of rans64.h Rans64EncPut by reciprocal multiplication.
+ * rows x stride int32 CDFs in, rows x stride records out (host memory). */
+int licos_rans_build_enc_table(const int32_t *cdf_host, const int32_t *cdf_len_host, int rows, int stride,
+                               void *table_out_host /* rows*stride*16 bytes */);
+
+/* ------------------------------------------------- 32-bit path (NCHW fp32)
+ * torch.nn.Conv2d.forward as instantiated by CompressAI models/google.py
+ * `conv()` and licos/model_utils.py:31-37.  Cross-correlation, square kernel. */
+int licos_conv2d_f32(const float *x, const float *w /*[Cout][Cin][K][K]*/, const float *bias /*nullable*/,
+                     float *y, int B, int Cin, int H, int W, int Cout, int K, int stride, int pad,
+                     int relu, void *stream);
+/* torch.nn.ConvTranspose2d.forward (CompressAI `deconv()`, licos/model_utils.py:38-45);
+ * w is [Cin][Cout][K][K]; Hout = (H-1)*stride - 2*pad + K + out_pad. */
+int licos_deconv2d_f32(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H,
+                       int W, int Cout, int K, int stride, int pad, int out_pad, int relu, void *stream);
+/* CompressAI ops/parametrizers.py NonNegativeParametrizer applied to GDN's
+ * beta (C) and gamma (C*C): out = max(raw, bound)^2 - pedestal. */
+int licos_gdn_reparam_f32(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
+                          float pedestal, float *beta_eff, float *gamma_eff, int C, void *stream);
+/* CompressAI layers/gdn.py GDN.forward: y = x * rsqrt(beta + gamma . x^2)
+ * (sqrt when inverse != 0).  x, y: [B][C][HW] fp32; gamma_eff [C][C]. */
+int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C,
+                  int HW, int inverse, void *stream);
+
+/* ------------------------------------------- entropy bottleneck (fp32 math)
+ * CompressAI entropy_models/entropy_models.py EntropyBottleneck, constructed at
+ * licos/model_utils.py:25-29.
+ *
+ * licos_eb_pack: softplus(matrices) / biases / tanh(factors) of all layers
+ * flattened per channel into `packed` [C][per_channel] (per_channel returned by
+ * licos_eb_packed_size).  nfilt = len(filters); filters e.g. {3,3,3,3}. */
+int licos_eb_packed_size(const int *filters_host, int nfilt);
+int licos_eb_pack(const float *const *matrices_dev_host_array, const float *const *biases_dev_host_array,
+                  const float *const *factors_dev_host_array, const int *filters_host, int nfilt, int C,
+                  float *packed, void *stream);
+/* EntropyModel.quantize.  y, noise, y_hat: [B][C][HW] fp32; medians [C].
+ * mode 0 ("dequantize"): y_hat = rint(y - m) + m (half-to-even, as torch.round)
+ * mode 1 ("noise"):      y_hat = y + noise
+ * mode 2 ("symbols"):    only symbols are written.
+ * symbols (nullable unless mode 2): int32, element (b, c, p) at
+ *   b*sym_stride_b + (c*HW + p)*sym_stride_i   (lets the coder read coalesced).
+ * y_hat_blk16 (nullable): also writes rint(y-m)+m as fp16 blk16 for the 16-bit g_s. */
+int licos_eb_quantize(const float *y, const float *medians, const float *noise, float *y_hat, int32_t *symbols,
+                      long sym_stride_b, long sym_stride_i, int mode, int B, int C, int HW, void *stream);
+/* EntropyBottleneck._likelihood + LowerBound: lik = max(sigmoid(F(v+.5)) -
+ * sigmoid(F(v-.5)), bound); form 0 = current releases, 1 = sign-flip variant
+ * of the 1.1/1.2-era releases.  sum_log2 (nullable, double[B], zeroed by the
+ * caller) receives sum over (c,p) of log2(lik) per image - the bpp numerator of
+ * /root/reference/eval_utils.py:172-186 and RateDistortionLoss. */
+int licos_eb_likelihood(const float *v, const float *packed, const int *filters_host, int nfilt, float *lik,
+                        float bound, int form, double *sum_log2, int B, int C, int HW, void *stream);
+/* symbols -> y_hat = float(symbol) + median (EntropyModel.dequantize);
+ * writes NCHW fp32 (nullable) and/or blk16 fp16 (nullable). */
+int licos_eb_dequantize(const int32_t *symbols, long sym_stride_b, long sym_stride_i, const float *medians,
+                        float *y_hat_nchw, void *y_hat_blk16, int B, int C, int H, int W, void *stream);
+
+/* mean-squared-error numerator: sum over all elements of (a-b)^2 into *out (double, zeroed by caller);
+ * /root/reference/eval_utils.py:145-156, RateDistortionLoss mse term.  clamp01 != 0 clamps `a` first. */
+int licos_reduce_sqdiff(const float *a, const float *b, long n, int clamp01, double *out, void *stream);
+
+/* ------------------------------------------------------------------- rANS
+ * CompressAI cpp_exts/rans/rans_interface.cpp RansEncoder.encode_with_indexes /
+ * RansDecoder.decode_with_indexes (reached from /root/reference/eval_utils.py:201),
+ * batched: one stream per image, one GPU lane per stream.
+ *
+ * symbols: int32, stream b, position i at b*sym_stride_b + i*sym_stride_i.
+ * indexes: nullable; same addressing; when NULL the CDF row of position i is
+ *          i / plane  (EntropyBottleneck._build_indexes: the channel id).
+ * cdf [rows][cdf_stride] int32, cdf_len[rows], offset[rows]: device copies of
+ *          _quantized_cdf / _cdf_length / _offset.
+ * enc_table: device copy of licos_rans_build_enc_table's output.
+ * words: scratch uint32 [cap_words][B] (word w of stream b at w*B + b, filled
+ *          from the top); nwords[B] receives each stream's word count;
+ *          status[0] is set non-zero if any stream overflowed cap_words. */
+int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i,
+                            int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                            const int32_t *offset, const void *enc_table, uint32_t *words, int cap_words,
+                            int32_t *nwords, int32_t *status, int B, void *stream);
+/* gathers each stream's words (in stream order) into one packed little-endian
+ * byte buffer: stream b occupies out[byte_off[b] .. byte_off[b] + 4*nwords[b]).
+ * byte_off[B] = exclusive prefix sum of 4*nwords (computed by the caller). */
+int licos_rans_compact(const uint32_t *words, int cap_words, const int32_t *nwords, const int64_t *byte_off,
+                       uint8_t *out, int B, void *stream);
+/* decoder: stream b = in[byte_off[b] .. byte_off[b+1]) ; writes symbols with the
+ * same addressing as above; status[0] non-zero if a stream ran past its end. */
+int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const int32_t *indexes,
+                            long sym_stride_b, long sym_stride_i, int n, int plane, const int32_t *cdf,
+                            int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int32_t *symbols,
+                            int32_t *status, int B, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LICOS_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of ``liblicos_hip.so`` (the C ABI declared in include/licos_hip.h).
+
+The HIP library is the product; there is no CPU fallback.  If the shared object
+is missing this module raises immediately with the build instruction.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblicos_hip.so")
+
+_c = ctypes
+_vp, _i, _l, _f = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/licos_hip.h
+SIGNATURES = {
+    "licos_last_error": (_c.c_char_p, []),
+    "licos_abi_version": (_i, []),
+    "licos_query": (_i, [_i, _vp]),
+    "licos_pmf_to_quantized_cdf": (_i, [_vp, _i, _i, _vp]),
+    "licos_rans_build_enc_table": (_i, [_vp, _vp, _i, _i, _vp]),
+    "licos_conv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_deconv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_gdn_reparam_f32": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _i, _vp]),
+    "licos_gdn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "licos_eb_packed_size": (_i, [_vp, _i]),
+    "licos_eb_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "licos_eb_quantize": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp]),
+    "licos_eb_likelihood": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
+    "licos_eb_dequantize": (_i, [_vp, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "licos_reduce_sqdiff": (_i, [_vp, _vp, _l, _i, _vp, _vp]),
+    "licos_rans_encode_batch": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "licos_rans_compact": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "licos_rans_decode_batch": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+}
+
+_lib = None
+
+
+class LicosError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise LicosError(
+            f"licos_amd: {SO_PATH} is missing - the HIP extension is the product and there is no CPU "
+            "fallback.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C licos_amd/csrc`)."
+        )
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.licos_abi_version() != 1:
+        raise LicosError("licos_amd: ABI version mismatch between Python host and liblicos_hip.so")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().licos_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        if rc == -3:
+            raise ValueError(msg)
+        raise LicosError(f"{what}: {msg} (code {rc})")
+    return rc

@@ -1,0 +1,38 @@
+// Shared helpers for the LICOS gfx950 library (internal; the public ABI is include/licos_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "licos_hip.h"
+
+namespace licos {
+
+std::string &last_error_ref();
+int fail(int code, const char *fmt, ...);
+
+#define LICOS_REQUIRE(cond, ...)                              \
+  do {                                                        \
+    if (!(cond)) return ::licos::fail(LICOS_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+#define LICOS_HIP_CHECK(expr)                                                                    \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return ::licos::fail(LICOS_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                           __FILE__, __LINE__);                                                  \
+  } while (0)
+
+// every launch goes through this: catches bad launch configurations immediately
+#define LICOS_LAUNCH_CHECK() LICOS_HIP_CHECK(hipGetLastError())
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+constexpr int WAVE = 64;
+
+}  // namespace licos

@@ -1,0 +1,320 @@
+// Entropy bottleneck kernels (fp32): parameter packing, quantise, factorised likelihood,
+// dequantise, and the reductions the loss / metrics need.
+//
+// Packed per-channel parameter record (licos_eb_pack), for filters f = (1, f1..fn, 1):
+//   for layer i = 0..n:  softplus(matrix_i) [f(i+1)][f(i)] row-major, bias_i [f(i+1)],
+//                        tanh(factor_i) [f(i+1)]   (factor block absent on the last layer)
+#include "common.hpp"
+
+namespace licos {
+
+constexpr int EB_MAX_LAYERS = 8;
+constexpr int EB_MAX_WIDTH = 16;
+
+struct EbShape {
+  int n_layers;              // len(filters) + 1
+  int f[EB_MAX_LAYERS + 1];  // (1, filters..., 1)
+  int per_channel;
+};
+
+static int make_shape(const int *filters, int nfilt, EbShape *s) {
+  if (!filters || nfilt < 1 || nfilt + 1 > EB_MAX_LAYERS) return -1;
+  s->n_layers = nfilt + 1;
+  s->f[0] = 1;
+  for (int i = 0; i < nfilt; ++i) {
+    if (filters[i] < 1 || filters[i] > EB_MAX_WIDTH) return -1;
+    s->f[i + 1] = filters[i];
+  }
+  s->f[nfilt + 1] = 1;
+  int n = 0;
+  for (int i = 0; i < s->n_layers; ++i) {
+    n += s->f[i + 1] * s->f[i] + s->f[i + 1];
+    if (i < s->n_layers - 1) n += s->f[i + 1];
+  }
+  s->per_channel = n;
+  return 0;
+}
+
+struct EbPackArgs {
+  const float *matrix[EB_MAX_LAYERS];
+  const float *bias[EB_MAX_LAYERS];
+  const float *factor[EB_MAX_LAYERS];
+};
+
+__device__ inline float softplus_f(float x) {
+  // torch.nn.functional.softplus (beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+__global__ void eb_pack_kernel(EbPackArgs a, EbShape s, int C, float *__restrict__ packed) {
+  const int c = blockIdx.x;
+  if (c >= C) return;
+  float *out = packed + (size_t)c * s.per_channel;
+  int base = 0;
+  for (int i = 0; i < s.n_layers; ++i) {
+    const int rows = s.f[i + 1], cols = s.f[i];
+    for (int e = threadIdx.x; e < rows * cols; e += blockDim.x)
+      out[base + e] = softplus_f(a.matrix[i][(size_t)c * rows * cols + e]);
+    base += rows * cols;
+    for (int e = threadIdx.x; e < rows; e += blockDim.x) out[base + e] = a.bias[i][(size_t)c * rows + e];
+    base += rows;
+    if (i < s.n_layers - 1) {
+      for (int e = threadIdx.x; e < rows; e += blockDim.x) out[base + e] = tanhf(a.factor[i][(size_t)c * rows + e]);
+      base += rows;
+    }
+  }
+}
+
+// ---- quantise ---------------------------------------------------------------------------------
+__global__ void eb_quantize_kernel(const float *__restrict__ y, const float *__restrict__ medians,
+                                   const float *__restrict__ noise, float *__restrict__ y_hat,
+                                   int32_t *__restrict__ symbols, long ssb, long ssi, int mode, int C, int HW,
+                                   long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(e % HW);
+    const int c = (int)((e / HW) % C);
+    const long b = e / ((long)HW * C);
+    const float v = y[e];
+    const float m = medians[c];
+    if (mode == 1) {
+      y_hat[e] = v + noise[e];
+    } else {
+      const float r = rintf(v - m);  // round-half-to-even, as torch.round
+      if (y_hat) y_hat[e] = r + m;
+      if (symbols) symbols[b * ssb + ((long)c * HW + p) * ssi] = (int32_t)r;
+    }
+  }
+}
+
+// ---- likelihood -------------------------------------------------------------------------------
+__device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Evaluates the cumulative logits F(v) of one channel; parameters in LDS (s_p).
+template <int F1, int F2, int F3, int F4>
+__device__ inline float eb_logits_fixed(const float *s_p, float v) {
+  // filters (F1,F2,F3,F4): five layers, all extents compile-time -> registers only
+  constexpr int f[6] = {1, F1, F2, F3, F4, 1};
+  float cur[EB_MAX_WIDTH], nxt[EB_MAX_WIDTH];
+  cur[0] = v;
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int rows = f[i + 1], cols = f[i];
+#pragma unroll
+    for (int r = 0; r < rows; ++r) {
+      // torch.matmul on (rows x cols) @ (cols x n): a dot product per output
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < cols; ++q) acc = fmaf(s_p[base + r * cols + q], cur[q], acc);
+      nxt[r] = acc + s_p[base + rows * cols + r];
+    }
+    base += rows * cols + rows;
+    if (i < 4) {
+#pragma unroll
+      for (int r = 0; r < rows; ++r) nxt[r] = nxt[r] + s_p[base + r] * tanhf(nxt[r]);
+      base += rows;
+    }
+#pragma unroll
+    for (int r = 0; r < rows; ++r) cur[r] = nxt[r];
+  }
+  return cur[0];
+}
+
+__device__ inline float eb_logits_generic(const float *s_p, const EbShape &s, float v) {
+  float cur[EB_MAX_WIDTH], nxt[EB_MAX_WIDTH];
+  cur[0] = v;
+  int base = 0;
+  for (int i = 0; i < s.n_layers; ++i) {
+    const int rows = s.f[i + 1], cols = s.f[i];
+    for (int r = 0; r < rows; ++r) {
+      float acc = 0.f;
+      for (int q = 0; q < cols; ++q) acc = fmaf(s_p[base + r * cols + q], cur[q], acc);
+      nxt[r] = acc + s_p[base + rows * cols + r];
+    }
+    base += rows * cols + rows;
+    if (i < s.n_layers - 1) {
+      for (int r = 0; r < rows; ++r) nxt[r] = nxt[r] + s_p[base + r] * tanhf(nxt[r]);
+      base += rows;
+    }
+    for (int r = 0; r < rows; ++r) cur[r] = nxt[r];
+  }
+  return cur[0];
+}
+
+// VARIANT: 0 generic, 1 = (3,3,3,3), 2 = (1,1,3,3), 3 = (13,13,3,3)
+template <int VARIANT>
+__global__ __launch_bounds__(256) void eb_likelihood_kernel(const float *__restrict__ v, const float *__restrict__ packed,
+                                                            EbShape s, float *__restrict__ lik, float bound, int form,
+                                                            double *__restrict__ sum_log2, int C, int HW) {
+  extern __shared__ float s_p[];
+  __shared__ double s_red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  for (int e = threadIdx.x; e < s.per_channel; e += blockDim.x) s_p[e] = packed[(size_t)c * s.per_channel + e];
+  __syncthreads();
+  const size_t plane = ((size_t)b * C + c) * HW;
+  double local = 0.0;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float x = v[plane + p];
+    float lo, up;
+    if (VARIANT == 1) { lo = eb_logits_fixed<3, 3, 3, 3>(s_p, x - 0.5f); up = eb_logits_fixed<3, 3, 3, 3>(s_p, x + 0.5f); }
+    else if (VARIANT == 2) { lo = eb_logits_fixed<1, 1, 3, 3>(s_p, x - 0.5f); up = eb_logits_fixed<1, 1, 3, 3>(s_p, x + 0.5f); }
+    else if (VARIANT == 3) { lo = eb_logits_fixed<13, 13, 3, 3>(s_p, x - 0.5f); up = eb_logits_fixed<13, 13, 3, 3>(s_p, x + 0.5f); }
+    else { lo = eb_logits_generic(s_p, s, x - 0.5f); up = eb_logits_generic(s_p, s, x + 0.5f); }
+    float l;
+    if (form == 0) {
+      l = sigmoid_f(up) - sigmoid_f(lo);
+    } else {
+      const float t = lo + up;
+      const float sg = (t > 0.f) ? -1.f : ((t < 0.f) ? 1.f : 0.f);
+      l = fabsf(sigmoid_f(sg * up) - sigmoid_f(sg * lo));
+    }
+    l = fmaxf(l, bound);
+    lik[plane + p] = l;
+    local += (double)log2f(l);
+  }
+  if (sum_log2) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_red[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+      atomicAdd(&sum_log2[b], t);
+    }
+  }
+}
+
+// ---- dequantise -------------------------------------------------------------------------------
+__global__ void eb_dequantize_kernel(const int32_t *__restrict__ symbols, long ssb, long ssi,
+                                     const float *__restrict__ medians, float *__restrict__ y_nchw,
+                                     _Float16 *__restrict__ y_blk, int C, int H, int W, long total) {
+  const int HW = H * W;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(e % HW);
+    const int c = (int)((e / HW) % C);
+    const long b = e / ((long)HW * C);
+    const float val = (float)symbols[b * ssb + ((long)c * HW + p) * ssi] + medians[c];
+    if (y_nchw) y_nchw[e] = val;
+    if (y_blk) {
+      const int C16 = (C + 15) / 16;
+      y_blk[(((size_t)b * C16 + (c >> 4)) * HW + p) * 16 + (c & 15)] = (_Float16)val;
+    }
+  }
+}
+
+// ---- squared-difference reduction ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_sqdiff_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                            long n, int clamp01, double *__restrict__ out) {
+  __shared__ double s_red[4];
+  double local = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float av = a[e];
+    if (clamp01) av = fminf(fmaxf(av, 0.f), 1.f);
+    const float d = av - b[e];
+    local += (double)(d * d);
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+}  // namespace licos
+
+using namespace licos;
+
+extern "C" {
+
+int licos_eb_packed_size(const int *filters, int nfilt) {
+  EbShape s;
+  if (make_shape(filters, nfilt, &s) != 0) return fail(LICOS_EINVAL, "eb: unsupported filters (need 1..%d layers of width 1..%d)", EB_MAX_LAYERS - 1, EB_MAX_WIDTH);
+  return s.per_channel;
+}
+
+int licos_eb_pack(const float *const *matrices, const float *const *biases, const float *const *factors,
+                  const int *filters, int nfilt, int C, float *packed, void *stream) {
+  EbShape s;
+  LICOS_REQUIRE(make_shape(filters, nfilt, &s) == 0, "eb_pack: unsupported filters");
+  LICOS_REQUIRE(matrices && biases && factors && packed && C > 0, "eb_pack: bad arguments");
+  EbPackArgs a{};
+  for (int i = 0; i < s.n_layers; ++i) {
+    a.matrix[i] = matrices[i];
+    a.bias[i] = biases[i];
+    a.factor[i] = (i < s.n_layers - 1) ? factors[i] : nullptr;
+    LICOS_REQUIRE(a.matrix[i] && a.bias[i] && (i == s.n_layers - 1 || a.factor[i]), "eb_pack: NULL parameter for layer %d", i);
+  }
+  hipLaunchKernelGGL(eb_pack_kernel, dim3(C), dim3(64), 0, as_stream(stream), a, s, C, packed);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_quantize(const float *y, const float *medians, const float *noise, float *y_hat, int32_t *symbols,
+                      long ssb, long ssi, int mode, int B, int C, int HW, void *stream) {
+  LICOS_REQUIRE(y && medians && B > 0 && C > 0 && HW > 0, "eb_quantize: bad arguments");
+  LICOS_REQUIRE(mode >= 0 && mode <= 2, "eb_quantize: mode %d", mode);
+  LICOS_REQUIRE(mode != 1 || (noise && y_hat), "eb_quantize: noise mode needs noise and y_hat");
+  LICOS_REQUIRE(mode != 0 || y_hat, "eb_quantize: dequantize mode needs y_hat");
+  LICOS_REQUIRE(mode != 2 || symbols, "eb_quantize: symbols mode needs symbols");
+  if (mode == 2) y_hat = nullptr;
+  if (mode == 1) symbols = nullptr;
+  const long total = (long)B * C * HW;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(eb_quantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, medians, noise, y_hat,
+                     symbols, ssb, ssi, mode, C, HW, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_likelihood(const float *v, const float *packed, const int *filters, int nfilt, float *lik, float bound,
+                        int form, double *sum_log2, int B, int C, int HW, void *stream) {
+  EbShape s;
+  LICOS_REQUIRE(make_shape(filters, nfilt, &s) == 0, "eb_likelihood: unsupported filters");
+  LICOS_REQUIRE(v && packed && lik && B > 0 && B <= 65535 && C > 0 && HW > 0, "eb_likelihood: bad arguments");
+  LICOS_REQUIRE(form == 0 || form == 1, "eb_likelihood: form %d", form);
+  int variant = 0;
+  if (nfilt == 4 && s.f[3] == 3 && s.f[4] == 3) {
+    if (s.f[1] == 3 && s.f[2] == 3) variant = 1;
+    else if (s.f[1] == 1 && s.f[2] == 1) variant = 2;
+    else if (s.f[1] == 13 && s.f[2] == 13) variant = 3;
+  }
+  const size_t lds = (size_t)s.per_channel * sizeof(float);
+  dim3 grid(C, B), block(HW >= 256 ? 256 : 64 * cdiv(HW, 64));
+  hipStream_t st = as_stream(stream);
+#define LICOS_EB_CASE(V)                                                                                          \
+  case V:                                                                                                         \
+    hipLaunchKernelGGL((eb_likelihood_kernel<V>), grid, block, lds, st, v, packed, s, lik, bound, form, sum_log2, \
+                       C, HW);                                                                                    \
+    break;
+  switch (variant) {
+    LICOS_EB_CASE(0)
+    LICOS_EB_CASE(1)
+    LICOS_EB_CASE(2)
+    LICOS_EB_CASE(3)
+  }
+#undef LICOS_EB_CASE
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float *medians, float *y_nchw,
+                        void *y_blk16, int B, int C, int H, int W, void *stream) {
+  LICOS_REQUIRE(symbols && medians && (y_nchw || y_blk16) && B > 0 && C > 0 && H > 0 && W > 0, "eb_dequantize: bad arguments");
+  const long total = (long)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(eb_dequantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), symbols, ssb, ssi, medians,
+                     y_nchw, static_cast<_Float16 *>(y_blk16), C, H, W, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_reduce_sqdiff(const float *a, const float *b, long n, int clamp01, double *out, void *stream) {
+  LICOS_REQUIRE(a && b && out && n > 0, "reduce_sqdiff: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(reduce_sqdiff_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, n, clamp01, out);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+// Batched rANS coder: one stream per image, one lane per stream.
+//
+// Stream format (bit-exact with CompressAI's RansEncoder/RansDecoder):
+// 64-bit state, L = 2^31, 32-bit little-endian words, 16-bit probabilities, 4-bit bypass nibbles
+// for values outside the tabulated range.  The recurrence is strictly sequential inside a
+// stream, so parallelism is across streams only: lane b of the grid owns stream b and walks its
+// symbols in reverse (the encoder emits words back to front).  Words are staged in an
+// interleaved scratch [word][stream] so that lanes advancing in lock-step write coalesced.
+#include "common.hpp"
+
+namespace licos {
+
+constexpr uint64_t RANS_L = 1ull << 31;
+
+struct EncRec { uint64_t rcp; uint32_t bias; uint16_t freq; uint16_t shift; };
+
+struct WordSink {
+  uint32_t *words;
+  int B, b, wp;
+  bool overflow;
+  __device__ inline void put(uint32_t w) {
+    if (wp > 0) { --wp; words[(size_t)wp * B + b] = w; }
+    else overflow = true;
+  }
+};
+
+__device__ inline void put_bits4(uint64_t &x, WordSink &sink, uint32_t val) {
+  // Rans64EncPutBits with nbits = 4: freq = 2^12, x_max = 2^59
+  if (x >= (1ull << 59)) { sink.put((uint32_t)x); x >>= 32; }
+  x = (x << 4) | val;
+}
+
+__global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t *__restrict__ symbols,
+                                                         const int32_t *__restrict__ indexes, long ssb, long ssi, int n,
+                                                         int plane, int cdf_stride, const int32_t *__restrict__ cdf_len,
+                                                         const int32_t *__restrict__ offset,
+                                                         const EncRec *__restrict__ table, uint32_t *__restrict__ words,
+                                                         int cap_words, int32_t *__restrict__ nwords,
+                                                         int32_t *__restrict__ status, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  WordSink sink{words, B, b, cap_words, false};
+  uint64_t x = RANS_L;
+  const int32_t *sp = symbols + (size_t)b * ssb;
+  const int32_t *ip = indexes ? indexes + (size_t)b * ssb : nullptr;
+  for (int i = n - 1; i >= 0; --i) {
+    const int32_t s = sp[(size_t)i * ssi];
+    const int c = ip ? ip[(size_t)i * ssi] : i / plane;
+    const int32_t max_value = cdf_len[c] - 2;
+    int32_t value = s - offset[c];
+    if (value < 0 || value >= max_value) {
+      const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
+      value = max_value;
+      int nb = 0;
+      while (nb < 8 && (raw >> (nb * 4)) != 0) ++nb;
+      // coding order is [symbol, count nibbles (15,15,..,rem), raw nibbles low->high]; emit reversed
+      for (int j = nb - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+      const int k15 = nb / 15, rem = nb - 15 * k15;
+      put_bits4(x, sink, (uint32_t)rem);
+      for (int t = 0; t < k15; ++t) put_bits4(x, sink, 15u);
+    }
+    const EncRec rec = table[(size_t)c * cdf_stride + value];
+    const uint32_t freq = rec.freq ? rec.freq : 65536u;
+    if (x >= ((uint64_t)freq << 47)) { sink.put((uint32_t)x); x >>= 32; }
+    const uint64_t q = __umul64hi(x, rec.rcp) >> rec.shift;
+    x = x + rec.bias + q * (uint64_t)(65536u - freq);
+  }
+  sink.put((uint32_t)(x >> 32));
+  sink.put((uint32_t)x);
+  nwords[b] = cap_words - sink.wp;
+  if (sink.overflow) atomicOr(status, 1);
+}
+
+__global__ __launch_bounds__(256) void rans_compact_kernel(const uint32_t *__restrict__ words, int cap_words,
+                                                           const int32_t *__restrict__ nwords,
+                                                           const int64_t *__restrict__ byte_off,
+                                                           uint32_t *__restrict__ out, int B) {
+  const int b = blockIdx.y;
+  const int nw = nwords[b];
+  uint32_t *dst = out + byte_off[b] / 4;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x)
+    dst[k] = words[(size_t)(cap_words - nw + k) * B + b];
+}
+
+struct WordSource {
+  const uint32_t *p;
+  int nw, pos;
+  bool over;
+  __device__ inline uint32_t next() {
+    if (pos < nw) return p[pos++];
+    over = true;
+    return 0u;
+  }
+};
+
+__device__ inline uint32_t get_bits4(uint64_t &x, WordSource &src) {
+  const uint32_t val = (uint32_t)(x & 15u);
+  x >>= 4;
+  if (x < RANS_L) x = (x << 32) | src.next();
+  return val;
+}
+
+__global__ __launch_bounds__(64) void rans_decode_kernel(const uint8_t *__restrict__ in,
+                                                         const int64_t *__restrict__ byte_off,
+                                                         const int32_t *__restrict__ indexes, long ssb, long ssi, int n,
+                                                         int plane, const int32_t *__restrict__ cdf, int cdf_stride,
+                                                         const int32_t *__restrict__ cdf_len,
+                                                         const int32_t *__restrict__ offset, int32_t *__restrict__ symbols,
+                                                         int32_t *__restrict__ status, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  WordSource src{reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), 0, false};
+  uint64_t x = (uint64_t)src.next();
+  x |= (uint64_t)src.next() << 32;
+  int32_t *sp = symbols + (size_t)b * ssb;
+  const int32_t *ip = indexes ? indexes + (size_t)b * ssb : nullptr;
+  for (int i = 0; i < n; ++i) {
+    const int c = ip ? ip[(size_t)i * ssi] : i / plane;
+    const int32_t *row = cdf + (size_t)c * cdf_stride;
+    const int len = cdf_len[c];
+    const int32_t max_value = len - 2;
+    const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+    int lo = 0, hi = len - 1;  // row[lo] <= cf < row[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+    }
+    const uint32_t start = (uint32_t)row[lo], range = (uint32_t)row[lo + 1] - start;
+    x = (uint64_t)range * (x >> 16) + cf - start;
+    if (x < RANS_L) x = (x << 32) | src.next();
+    int32_t value = lo;
+    if (value == max_value) {
+      uint32_t val = get_bits4(x, src);
+      int nb = (int)val;
+      while (val == 15u && nb < 64) { val = get_bits4(x, src); nb += (int)val; }
+      uint32_t raw = 0;
+      for (int j = 0; j < nb; ++j) {
+        const uint32_t nib = get_bits4(x, src);
+        if (j < 8) raw |= nib << (j * 4);
+      }
+      value = (int32_t)(raw >> 1);
+      value = (raw & 1u) ? -value - 1 : value + max_value;
+    }
+    sp[(size_t)i * ssi] = value + offset[c];
+  }
+  if (src.over) atomicOr(status, 1);
+}
+
+}  // namespace licos
+
+using namespace licos;
+
+extern "C" {
+
+int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long ssb, long ssi, int n, int plane,
+                            const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
+                            const void *enc_table, uint32_t *words, int cap_words, int32_t *nwords, int32_t *status,
+                            int B, void *stream) {
+  (void)cdf;
+  LICOS_REQUIRE(symbols && cdf_len && offset && enc_table && words && nwords && status, "rans_encode_batch: NULL buffer");
+  LICOS_REQUIRE(B > 0 && n > 0 && cap_words >= 2 && cdf_stride > 1, "rans_encode_batch: bad sizes B=%d n=%d cap=%d", B, n, cap_words);
+  LICOS_REQUIRE(indexes || plane > 0, "rans_encode_batch: need indexes or a plane size");
+  hipLaunchKernelGGL(rans_encode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), symbols, indexes, ssb, ssi,
+                     n, plane, cdf_stride, cdf_len, offset, static_cast<const EncRec *>(enc_table), words, cap_words,
+                     nwords, status, B);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_rans_compact(const uint32_t *words, int cap_words, const int32_t *nwords, const int64_t *byte_off,
+                       uint8_t *out, int B, void *stream) {
+  LICOS_REQUIRE(words && nwords && byte_off && out && B > 0 && B <= 65535 && cap_words > 0, "rans_compact: bad arguments");
+  LICOS_REQUIRE(((uintptr_t)out & 3) == 0, "rans_compact: out must be 4-byte aligned");
+  hipLaunchKernelGGL(rans_compact_kernel, dim3(cdiv(cap_words, 256) < 8 ? cdiv(cap_words, 256) : 8, B), dim3(256), 0,
+                     as_stream(stream), words, cap_words, nwords, byte_off, reinterpret_cast<uint32_t *>(out), B);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const int32_t *indexes, long ssb, long ssi,
+                            int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                            const int32_t *offset, int32_t *symbols, int32_t *status, int B, void *stream) {
+  LICOS_REQUIRE(in && byte_off && cdf && cdf_len && offset && symbols && status, "rans_decode_batch: NULL buffer");
+  LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
+  LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
+  LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
+  hipLaunchKernelGGL(rans_decode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), in, byte_off, indexes, ssb,
+                     ssi, n, plane, cdf, cdf_stride, cdf_len, offset, symbols, status, B);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,291 @@
+"""EntropyBottleneck with CompressAI's constructor, attributes, parameter names and
+methods (``entropy_models/entropy_models.py``), as LICOS builds it at
+/root/reference/licos/model_utils.py:25-29 (``EntropyBottleneck(channels=, filters=)``)
+and drives it at eval_script.py:72 (``update()``) and eval_utils.py:200-201
+(``forward`` / ``compress``).
+
+Device work (quantise, likelihood, rANS encode/decode, dequantise) runs in the HIP
+kernels of licos_amd/csrc/{eb,rans}.hip.  ``update()`` is host logic exactly as in
+the reference: the pmf is evaluated once per model in fp32 on the host so that the
+integer CDF tables are reproducible, then quantised by the C-ABI
+``licos_pmf_to_quantized_cdf``.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import LowerBound
+
+
+class EntropyBottleneck(nn.Module):
+    def __init__(self, channels, *args, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3),
+                 likelihood_bound=1e-9, entropy_coder_precision=16, likelihood_form="plain", **kwargs):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        if likelihood_form not in ("plain", "signflip"):
+            raise ValueError("likelihood_form must be 'plain' or 'signflip'")
+        self.likelihood_form = likelihood_form
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        self.matrices = nn.ParameterList()
+        self.biases = nn.ParameterList()
+        self.factors = nn.ParameterList()
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / f[i + 1]))
+            matrix = torch.Tensor(channels, f[i + 1], f[i])
+            matrix.data.fill_(init)
+            self.matrices.append(nn.Parameter(matrix))
+            bias = torch.Tensor(channels, f[i + 1], 1)
+            nn.init.uniform_(bias, -0.5, 0.5)
+            self.biases.append(nn.Parameter(bias))
+            if i < len(self.filters):
+                factor = torch.Tensor(channels, f[i + 1], 1)
+                nn.init.zeros_(factor)
+                self.factors.append(nn.Parameter(factor))
+
+        self.quantiles = nn.Parameter(torch.Tensor(channels, 1, 3))
+        init = torch.Tensor([-self.init_scale, 0, self.init_scale])
+        self.quantiles.data = init.repeat(self.quantiles.size(0), 1, 1)
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self._packed_key = None
+        self._packed = None
+        self._coder_key = None
+        self._coder = None
+
+    # ------------------------------------------------------------------ state_dict compatibility
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        # older CompressAI releases name the MLP parameters _matrix{i}/_bias{i}/_factor{i}
+        for i in range(len(self.filters) + 1):
+            for old, new in (("_matrix", "matrices"), ("_bias", "biases"), ("_factor", "factors")):
+                k_old, k_new = f"{prefix}{old}{i:d}", f"{prefix}{new}.{i:d}"
+                if k_old in state_dict and k_new not in state_dict:
+                    state_dict[k_new] = state_dict.pop(k_old)
+        # the integer tables change size with update(); adopt the checkpoint's shapes
+        for name in ("_offset", "_quantized_cdf", "_cdf_length"):
+            k = prefix + name
+            if k in state_dict:
+                buf = getattr(self, name)
+                if buf.shape != state_dict[k].shape:
+                    setattr(self, name, torch.empty(state_dict[k].shape, dtype=buf.dtype, device=buf.device))
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        self._coder_key = None
+
+    # ------------------------------------------------------------------ torch-level definitions
+    def _get_medians(self):
+        return self.quantiles[:, :, 1:2]
+
+    def _logits_cumulative(self, inputs, stop_gradient=False):
+        """Host/autograd definition (used by update() on the host and by loss())."""
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            matrix = self.matrices[i]
+            if stop_gradient:
+                matrix = matrix.detach()
+            logits = torch.matmul(F.softplus(matrix), logits)
+            bias = self.biases[i]
+            if stop_gradient:
+                bias = bias.detach()
+            logits = logits + bias
+            if i < len(self.filters):
+                factor = self.factors[i]
+                if stop_gradient:
+                    factor = factor.detach()
+                logits = logits + torch.tanh(factor) * torch.tanh(logits)
+        return logits
+
+    def loss(self):
+        """Auxiliary loss on the quantiles (licos/train.py:198,289 via model.aux_loss())."""
+        logits = self._logits_cumulative(self.quantiles, stop_gradient=True)
+        return torch.abs(logits - self.target).sum()
+
+    # ------------------------------------------------------------------ tables (host, once per model)
+    def update(self, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        with torch.no_grad():
+            host = {k: v.detach().to("cpu", torch.float32) for k, v in
+                    (("q", self.quantiles),) + tuple((f"m{i}", m) for i, m in enumerate(self.matrices))
+                    + tuple((f"b{i}", b) for i, b in enumerate(self.biases))
+                    + tuple((f"f{i}", f) for i, f in enumerate(self.factors))}
+            q = host["q"]
+            medians = q[:, 0, 1]
+            minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+            maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+            offset = -minima
+            pmf_start = medians - minima
+            pmf_length = maxima + minima + 1
+            max_length = int(pmf_length.max().item())
+            samples = torch.arange(max_length)
+            samples = samples[None, :] + pmf_start[:, None, None]
+
+            def logits(v):
+                out = v
+                n = len(self.filters) + 1
+                for i in range(n):
+                    out = torch.matmul(F.softplus(host[f"m{i}"]), out)
+                    out = out + host[f"b{i}"]
+                    if i < n - 1:
+                        out = out + torch.tanh(host[f"f{i}"]) * torch.tanh(out)
+                return out
+
+            lower = logits(samples - 0.5)
+            upper = logits(samples + 0.5)
+            if self.likelihood_form == "plain":
+                pmf = torch.sigmoid(upper) - torch.sigmoid(lower)
+            else:
+                sign = -torch.sign(lower + upper)
+                pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+            pmf = pmf[:, 0, :]
+            tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+            cdf = np.zeros((self.channels, max_length + 2), dtype=np.int32)
+            for c in range(self.channels):
+                prob = torch.cat((pmf[c, : pmf_length[c]], tail_mass[c]), dim=0).numpy()
+                row = ops.pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+                cdf[c, : row.size] = row
+        self._offset = offset.to(dev)
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._coder_key = None
+        return True
+
+    def _check_cdfs(self):
+        if self._offset.numel() == 0:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if self._quantized_cdf.dim() != 2:
+            raise ValueError(f"Invalid CDF size {tuple(self._quantized_cdf.size())}")
+        if self._cdf_length.numel() != self._quantized_cdf.size(0) or self._offset.numel() != self._quantized_cdf.size(0):
+            raise ValueError("Invalid offsets / CDF lengths size")
+
+    def coder_tables(self):
+        """Device tables for the coder kernels: (cdf, cdf_len, offset, enc_table)."""
+        self._check_cdfs()
+        key = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, tuple(self._quantized_cdf.shape),
+               str(self._quantized_cdf.device))
+        if self._coder_key != key:
+            cdf_h = self._quantized_cdf.detach().cpu().numpy()
+            len_h = self._cdf_length.detach().cpu().numpy()
+            table = ops.rans_build_enc_table(cdf_h, len_h)
+            dev = self._quantized_cdf.device
+            self._coder = (self._quantized_cdf.contiguous(), self._cdf_length.contiguous(), self._offset.contiguous(),
+                           torch.from_numpy(table).to(dev))
+            self._coder_key = key
+        return self._coder
+
+    # ------------------------------------------------------------------ device path
+    def packed_params(self):
+        key = tuple((p.data_ptr(), p._version) for p in list(self.matrices) + list(self.biases) + list(self.factors))
+        if self._packed_key != key:
+            self._packed = ops.eb_pack([m.detach() for m in self.matrices], [b.detach() for b in self.biases],
+                                       [f.detach() for f in self.factors], self.filters, self.channels)
+            self._packed_key = key
+        return self._packed
+
+    def medians_vec(self):
+        return self.quantiles.detach()[:, 0, 1].contiguous()
+
+    def forward(self, x, training=None, noise=None, sum_log2=None):
+        """(y_hat, likelihoods), both shaped like x (B, C, ...).  ``noise`` (optional, same shape)
+        replaces the internally drawn U(-1/2, 1/2) sample in training mode."""
+        if training is None:
+            training = self.training
+        x = x.contiguous()
+        if x.shape[1] != self.channels:
+            raise ValueError(f"expected {self.channels} channels, got {x.shape[1]}")
+        if training:
+            if noise is None:
+                noise = torch.empty_like(x).uniform_(-0.5, 0.5)
+            outputs = ops.eb_quantize(x, self.medians_vec(), "noise", noise=noise.contiguous())
+        else:
+            outputs = ops.eb_quantize(x, self.medians_vec(), "dequantize")
+        bound = self.likelihood_lower_bound.bound_value if self.use_likelihood_bound else 0.0
+        lik = ops.eb_likelihood(outputs, self.packed_params(), self.filters, bound,
+                                0 if self.likelihood_form == "plain" else 1, sum_log2)
+        return outputs, lik
+
+    def _symbols_interleaved(self, x):
+        """round(x - median) as int32 in the coder's [position][stream] layout."""
+        b = x.shape[0]
+        n = x[0].numel()
+        sym = torch.empty((n, b), device=x.device, dtype=torch.int32)
+        ops.eb_quantize(x.contiguous(), self.medians_vec(), "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=b)
+        return sym
+
+    def encode_symbols(self, sym, batch, n, plane, cap_words=None):
+        """sym: int32 [n][batch] on the device.  Returns (packed uint8 device tensor, byte offsets (host,
+        int64 [batch+1]))."""
+        cdf, cdf_len, offset, table = self.coder_tables()
+        if cap_words is None:
+            cap_words = n // 2 + 64
+        for attempt in range(2):
+            words, nwords, status = ops.rans_encode_batch(sym, 1, batch, n, plane, cdf, cdf_len, offset, table,
+                                                          cap_words, batch)
+            host = torch.cat((nwords, status)).cpu().numpy()  # one D2H, synchronises the stream
+            if host[-1] == 0:
+                break
+            if attempt == 1:
+                raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
+            cap_words = 2 * n + 8  # worst case: < 2 words per symbol
+        byte_off = np.zeros(batch + 1, dtype=np.int64)
+        np.cumsum(host[:batch].astype(np.int64) * 4, out=byte_off[1:])
+        off_dev = torch.from_numpy(byte_off).to(sym.device)
+        packed = ops.rans_compact(words, nwords, off_dev, int(byte_off[-1]))
+        return packed, byte_off
+
+    def compress(self, x):
+        """List of B byte strings (one rANS stream per image), CompressAI's format."""
+        self._check_cdfs()
+        if x.dim() < 3:
+            raise ValueError("Invalid `inputs` size. Expected a tensor with at least 3 dimensions.")
+        b = x.shape[0]
+        n = x[0].numel()
+        plane = x[0, 0].numel()
+        sym = self._symbols_interleaved(x)
+        packed, byte_off = self.encode_symbols(sym, b, n, plane)
+        host = packed.cpu().numpy()
+        return [host[byte_off[i]:byte_off[i + 1]].tobytes() for i in range(b)]
+
+    @staticmethod
+    def pack_strings(strings, device):
+        lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=len(strings))
+        if np.any(lens % 4) or np.any(lens < 8):
+            raise ValueError("licos_amd: every rANS string must be a whole number (>= 2) of 32-bit words")
+        byte_off = np.zeros(len(strings) + 1, dtype=np.int64)
+        np.cumsum(lens, out=byte_off[1:])
+        data = np.frombuffer(b"".join(strings), dtype=np.uint8)
+        return torch.from_numpy(data.copy()).to(device), torch.from_numpy(byte_off).to(device)
+
+    def decode_symbols(self, data, byte_off, batch, n, plane):
+        cdf, cdf_len, offset, _ = self.coder_tables()
+        sym = torch.empty((n, batch), device=data.device, dtype=torch.int32)
+        status = ops.rans_decode_batch(data, byte_off, 1, batch, n, plane, cdf, cdf_len, offset, sym, batch)
+        return sym, status
+
+    def decompress(self, strings, size):
+        """strings: list of B byte strings; size: spatial (H, W).  Returns y_hat (B, C, H, W)."""
+        self._check_cdfs()
+        b = len(strings)
+        c = self._quantized_cdf.size(0)
+        h, w = int(size[0]), int(size[1])
+        data, byte_off = self.pack_strings(strings, self._quantized_cdf.device)
+        sym, status = self.decode_symbols(data, byte_off, b, c * h * w, h * w)
+        out = ops.eb_dequantize(sym, 1, b, self.medians_vec(), b, c, h, w)
+        if int(status.item()) != 0:
+            raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+        return out

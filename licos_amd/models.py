@@ -1,0 +1,137 @@
+"""FactorizedPrior with CompressAI's nn.Module surface (``models/google.py``,
+``models/base.py``), the object /root/reference/licos/model_utils.py:19 obtains from
+``image_models[...]`` and that train.py:190 / eval_utils.py:200-201 drive through
+``forward`` / ``compress`` / ``decompress`` / ``update`` / ``aux_loss``.
+
+``g_a`` / ``g_s`` are indexable, item-assignable ``nn.Sequential`` containers of stock
+``torch.nn.Conv2d`` / ``ConvTranspose2d`` modules (parameter holders - LICOS swaps
+``g_a[0]`` and ``g_s[6]`` for fresh stock modules, model_utils.py:31-45) and ``GDN``
+modules.  Their ``forward`` never calls torch's convolutions: it launches the HIP
+kernels with whatever weights currently sit in the slots.
+
+precision:
+  "fp32"  direct fp32 kernels; latents/likelihoods within 1e-5 of the CPU reference
+          arithmetic and identical rANS bytes (parity path);
+  "fp16"  fused MFMA pipeline (throughput path, BASELINE.json configs[1]).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .entropy_models import EntropyBottleneck
+from .layers import GDN, conv, conv_geometry, deconv
+
+
+class TransformSequential(nn.Sequential):
+    """nn.Sequential whose forward runs the HIP transform pipeline."""
+
+    precision = "fp32"
+
+    def forward(self, x):
+        if self.precision == "fp16":
+            from .engine import run_chain_fp16
+            return run_chain_fp16(self, x)
+        return run_chain_fp32(self, x)
+
+
+def run_chain_fp32(seq, x):
+    if x.dtype != torch.float32:
+        raise ValueError("licos_amd: inputs must be float32")
+    x = x.contiguous()
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        if isinstance(m, nn.ConvTranspose2d):
+            k, s, p, op = conv_geometry(m)
+            x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
+        elif isinstance(m, nn.Conv2d):
+            k, s, p = conv_geometry(m)
+            x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu)
+        elif isinstance(m, GDN):
+            x = m(x)
+            relu = False
+        else:
+            raise TypeError(f"licos_amd: unsupported module in transform: {type(m).__name__}")
+        i += 2 if relu else 1
+    return x
+
+
+class CompressionModel(nn.Module):
+    """CompressAI ``models/base.py`` CompressionModel surface."""
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def update(self, force=False):
+        updated = False
+        for m in self.children():
+            if isinstance(m, EntropyBottleneck):
+                updated |= m.update(force=force)
+        return updated
+
+    def set_precision(self, precision):
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        self.precision = precision
+        return self
+
+
+class FactorizedPrior(CompressionModel):
+    def __init__(self, N, M, precision="fp32", **kwargs):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(M)
+        self.g_a = TransformSequential(conv(3, N), GDN(N), conv(N, N), GDN(N), conv(N, N), GDN(N), conv(N, M))
+        self.g_s = TransformSequential(deconv(M, N), GDN(N, inverse=True), deconv(N, N), GDN(N, inverse=True),
+                                       deconv(N, N), GDN(N, inverse=True), deconv(N, 3))
+        self.N = N
+        self.M = M
+        self.precision = precision
+
+    @property
+    def downsampling_factor(self):
+        return 2 ** 4
+
+    def _sync_precision(self):
+        self.g_a.precision = self.precision
+        self.g_s.precision = self.precision
+
+    def forward(self, x, noise=None):
+        self._sync_precision()
+        y = self.g_a(x)
+        y_hat, y_likelihoods = self.entropy_bottleneck(y, noise=noise)
+        x_hat = self.g_s(y_hat)
+        return {"x_hat": x_hat, "likelihoods": {"y": y_likelihoods}}
+
+    def compress(self, x):
+        self._sync_precision()
+        y = self.g_a(x)
+        y_strings = self.entropy_bottleneck.compress(y)
+        return {"strings": [y_strings], "shape": y.size()[-2:]}
+
+    def decompress(self, strings, shape):
+        assert isinstance(strings, list) and len(strings) == 1
+        self._sync_precision()
+        y_hat = self.entropy_bottleneck.decompress(strings[0], shape)
+        x_hat = self.g_s(y_hat).clamp_(0, 1)
+        return {"x_hat": x_hat}
+
+    @classmethod
+    def from_state_dict(cls, state_dict):
+        N = state_dict["g_a.0.weight"].size(0)
+        M = state_dict["g_a.6.weight"].size(0)
+        net = cls(N, M)
+        net.load_state_dict(state_dict)
+        return net
+
+
+class FactorizedPriorReLU(FactorizedPrior):
+    """bmshj2018-factorized-relu: every GDN replaced by ReLU (CompressAI models/google.py)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__(N=N, M=M, **kwargs)
+        self.g_a = TransformSequential(conv(3, N), nn.ReLU(inplace=True), conv(N, N), nn.ReLU(inplace=True),
+                                       conv(N, N), nn.ReLU(inplace=True), conv(N, M))
+        self.g_s = TransformSequential(deconv(M, N), nn.ReLU(inplace=True), deconv(N, N), nn.ReLU(inplace=True),
+                                       deconv(N, N), nn.ReLU(inplace=True), deconv(N, 3))

@@ -1,0 +1,226 @@
+"""Tensor-level wrappers over the C ABI (include/licos_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute
+step is one of the hand-written HIP kernels.  All wrappers refuse CPU tensors -
+there is deliberately no CPU fallback in the product.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.LicosError(
+                "licos_amd: the HIP path needs tensors on a ROCm device (MI355X); got a CPU tensor. "
+                "There is no CPU fallback in this package."
+            )
+        if not t.is_contiguous():
+            raise ValueError("licos_amd: tensor must be contiguous")
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise ValueError(f"licos_amd: expected float32, got {t.dtype}")
+    return t
+
+
+# ----------------------------------------------------------------------------- host-side helpers
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """CompressAI ``_CXX.pmf_to_quantized_cdf`` equivalent (host, int32 out)."""
+    pmf = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    out = np.zeros(pmf.size + 1, dtype=np.int32)
+    rc = _lib.load().licos_pmf_to_quantized_cdf(pmf.ctypes.data, pmf.size, precision, out.ctypes.data)
+    _lib.check(rc, "pmf_to_quantized_cdf")
+    return out
+
+
+def rans_build_enc_table(cdf, cdf_len):
+    cdf = np.ascontiguousarray(np.asarray(cdf, dtype=np.int32))
+    cdf_len = np.ascontiguousarray(np.asarray(cdf_len, dtype=np.int32))
+    rows, stride = cdf.shape
+    table = np.zeros((rows, stride, 16), dtype=np.uint8)
+    rc = _lib.load().licos_rans_build_enc_table(cdf.ctypes.data, cdf_len.ctypes.data, rows, stride, table.ctypes.data)
+    _lib.check(rc, "rans_build_enc_table")
+    return table
+
+
+def query(device=0):
+    class Props(ctypes.Structure):
+        _fields_ = [("compute_units", ctypes.c_int), ("wavefront_size", ctypes.c_int),
+                    ("lds_bytes_per_cu", ctypes.c_int), ("clock_khz", ctypes.c_int),
+                    ("hbm_bytes", ctypes.c_size_t), ("arch", ctypes.c_char * 32)]
+    p = Props()
+    _lib.check(_lib.load().licos_query(device, ctypes.addressof(p)), "query")
+    return {"compute_units": p.compute_units, "wavefront_size": p.wavefront_size,
+            "lds_bytes_per_cu": p.lds_bytes_per_cu, "clock_khz": p.clock_khz, "hbm_bytes": p.hbm_bytes,
+            "arch": p.arch.decode()}
+
+
+# ----------------------------------------------------------------------------- 32-bit path
+def conv2d_f32(x, w, bias, stride, pad, relu=False):
+    _dev(x, w, bias)
+    b, cin, h, wd = x.shape
+    cout, cin_w, k, k2 = w.shape
+    if cin_w != cin or k != k2:
+        raise ValueError(f"conv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
+    rc = _lib.load().licos_conv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride, pad,
+                                      int(relu), _stream())
+    _lib.check(rc, "conv2d_f32")
+    return y
+
+
+def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False):
+    _dev(x, w, bias)
+    b, cin, h, wd = x.shape
+    cin_w, cout, k, k2 = w.shape
+    if cin_w != cin or k != k2:
+        raise ValueError(f"deconv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    ho, wo = (h - 1) * stride - 2 * pad + k + out_pad, (wd - 1) * stride - 2 * pad + k + out_pad
+    y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
+    rc = _lib.load().licos_deconv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride,
+                                        pad, out_pad, int(relu), _stream())
+    _lib.check(rc, "deconv2d_f32")
+    return y
+
+
+def gdn_reparam_f32(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
+    _dev(beta_raw, gamma_raw)
+    c = beta_raw.numel()
+    beta = torch.empty_like(beta_raw)
+    gamma = torch.empty_like(gamma_raw)
+    rc = _lib.load().licos_gdn_reparam_f32(_p(_f32(beta_raw)), _p(_f32(gamma_raw)), beta_bound, gamma_bound, pedestal,
+                                           _p(beta), _p(gamma), c, _stream())
+    _lib.check(rc, "gdn_reparam_f32")
+    return beta, gamma
+
+
+def gdn_f32(x, gamma_eff, beta_eff, inverse=False):
+    _dev(x, gamma_eff, beta_eff)
+    b, c = x.shape[:2]
+    hw = x[0, 0].numel()
+    y = torch.empty_like(x)
+    rc = _lib.load().licos_gdn_f32(_p(_f32(x)), _p(gamma_eff), _p(beta_eff), _p(y), b, c, hw, int(inverse), _stream())
+    _lib.check(rc, "gdn_f32")
+    return y
+
+
+# ----------------------------------------------------------------------------- entropy bottleneck
+def _filters_arr(filters):
+    return (ctypes.c_int * len(filters))(*[int(f) for f in filters])
+
+
+def eb_packed_size(filters):
+    arr = _filters_arr(filters)
+    return _lib.check(_lib.load().licos_eb_packed_size(ctypes.cast(arr, ctypes.c_void_p), len(filters)), "eb_packed_size")
+
+
+def eb_pack(matrices, biases, factors, filters, channels):
+    _dev(*matrices, *biases, *factors)
+    n = len(filters) + 1
+    per = eb_packed_size(filters)
+    packed = torch.empty((channels, per), device=matrices[0].device, dtype=torch.float32)
+    PA = ctypes.c_void_p * n
+    ma = PA(*[m.data_ptr() for m in matrices])
+    ba = PA(*[b.data_ptr() for b in biases])
+    fa = PA(*([f.data_ptr() for f in factors] + [0]))
+    arr = _filters_arr(filters)
+    rc = _lib.load().licos_eb_pack(ctypes.cast(ma, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
+                                   ctypes.cast(fa, ctypes.c_void_p), ctypes.cast(arr, ctypes.c_void_p), len(filters),
+                                   channels, _p(packed), _stream())
+    _lib.check(rc, "eb_pack")
+    return packed
+
+
+def eb_quantize(y, medians, mode, noise=None, symbols=None, sym_stride_b=0, sym_stride_i=1, want_y_hat=True):
+    """mode: 'dequantize' | 'noise' | 'symbols'.  y: (B, C, *spatial) fp32."""
+    _dev(y, medians, noise, symbols)
+    b, c = y.shape[:2]
+    hw = y[0, 0].numel()
+    m = {"dequantize": 0, "noise": 1, "symbols": 2}[mode]
+    y_hat = torch.empty_like(y) if (want_y_hat and m != 2) else None
+    rc = _lib.load().licos_eb_quantize(_p(_f32(y)), _p(_f32(medians)), _p(noise), _p(y_hat), _p(symbols),
+                                       sym_stride_b, sym_stride_i, m, b, c, hw, _stream())
+    _lib.check(rc, "eb_quantize")
+    return y_hat
+
+
+def eb_likelihood(v, packed, filters, bound, form=0, sum_log2=None):
+    _dev(v, packed, sum_log2)
+    b, c = v.shape[:2]
+    hw = v[0, 0].numel()
+    lik = torch.empty_like(v)
+    arr = _filters_arr(filters)
+    rc = _lib.load().licos_eb_likelihood(_p(_f32(v)), _p(packed), ctypes.cast(arr, ctypes.c_void_p), len(filters),
+                                         _p(lik), bound, form, _p(sum_log2), b, c, hw, _stream())
+    _lib.check(rc, "eb_likelihood")
+    return lik
+
+
+def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want_nchw=True, blk16=None):
+    _dev(symbols, medians, blk16)
+    y = torch.empty((b, c, h, w), device=symbols.device, dtype=torch.float32) if want_nchw else None
+    rc = _lib.load().licos_eb_dequantize(_p(symbols), sym_stride_b, sym_stride_i, _p(medians), _p(y), _p(blk16),
+                                         b, c, h, w, _stream())
+    _lib.check(rc, "eb_dequantize")
+    return y
+
+
+def reduce_sqdiff(a, b, clamp01=False):
+    _dev(a, b)
+    out = torch.zeros(1, device=a.device, dtype=torch.float64)
+    rc = _lib.load().licos_reduce_sqdiff(_p(_f32(a)), _p(_f32(b)), a.numel(), int(clamp01), _p(out), _stream())
+    _lib.check(rc, "reduce_sqdiff")
+    return out
+
+
+# ----------------------------------------------------------------------------- rANS
+def rans_encode_batch(symbols, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, enc_table, cap_words,
+                      batch, indexes=None):
+    """Returns (words scratch [cap_words, B] u32, nwords [B] i32, status [1] i32) on the device."""
+    _dev(symbols, cdf, cdf_len, offset, enc_table, indexes)
+    dev = symbols.device
+    words = torch.empty((cap_words, batch), device=dev, dtype=torch.int32)
+    nwords = torch.empty(batch, device=dev, dtype=torch.int32)
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    rc = _lib.load().licos_rans_encode_batch(_p(symbols), _p(indexes), sym_stride_b, sym_stride_i, n, plane, _p(cdf),
+                                             cdf.shape[1], _p(cdf_len), _p(offset), _p(enc_table), _p(words),
+                                             cap_words, _p(nwords), _p(status), batch, _stream())
+    _lib.check(rc, "rans_encode_batch")
+    return words, nwords, status
+
+
+def rans_compact(words, nwords, byte_off, total_bytes):
+    _dev(words, nwords, byte_off)
+    cap, batch = words.shape
+    out = torch.empty(max(int(total_bytes), 4), device=words.device, dtype=torch.uint8)
+    rc = _lib.load().licos_rans_compact(_p(words), cap, _p(nwords), _p(byte_off), _p(out), batch, _stream())
+    _lib.check(rc, "rans_compact")
+    return out
+
+
+def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, symbols, batch,
+                      indexes=None):
+    _dev(data, byte_off, cdf, cdf_len, offset, symbols, indexes)
+    status = torch.zeros(1, device=data.device, dtype=torch.int32)
+    rc = _lib.load().licos_rans_decode_batch(_p(data), _p(byte_off), _p(indexes), sym_stride_b, sym_stride_i, n, plane,
+                                             _p(cdf), cdf.shape[1], _p(cdf_len), _p(offset), _p(symbols), _p(status),
+                                             batch, _stream())
+    _lib.check(rc, "rans_decode_batch")
+    return status

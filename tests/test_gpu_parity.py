@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors.  Tolerances: latents/likelihoods 1e-5 relative (north_star), integer work bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import licos_amd
+from licos_amd import ops
+from oracle import model as om
+from oracle import rans
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k,s", [(3, 128, 64, 64, 5, 2), (13, 128, 37, 53, 5, 2), (1, 128, 32, 32, 5, 2),
+                                               (128, 192, 32, 32, 5, 2), (20, 24, 19, 23, 3, 1), (7, 5, 9, 9, 1, 1)])
+def test_conv2d_f32(cin, cout, h, w, k, s):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x, wt, b, stride=s, padding=k // 2)
+    out = ops.conv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), s, k // 2)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 4, 4), (128, 128, 16, 16), (128, 3, 32, 32), (128, 13, 9, 21),
+                                          (128, 1, 16, 16)])
+def test_deconv2d_f32(cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 5, 5, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    out = ops.deconv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), 2, 2, 1)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("c,hw", [(128, (16, 16)), (192, (5, 7))])
+def test_gdn_f32(c, hw, inverse):
+    sd = {}
+    om._gdn_init(sd, "g.", c)
+    g = torch.Generator().manual_seed(c)
+    sd["g.gamma"] = sd["g.gamma"] + 0.05 * torch.rand(c, c, generator=g)
+    sd["g.beta"] = sd["g.beta"] * (0.5 + torch.rand(c, generator=g))
+    x = 3 * torch.randn(2, c, *hw, generator=g)
+    ref = om.gdn(x, sd, "g.", inverse=inverse)
+    m = licos_amd.GDN(c, inverse=inverse)
+    m.load_state_dict({k[2:]: v for k, v in sd.items()})
+    out = m.to(DEV)(x.to(DEV))
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cin", [3, 1, 13])
+def test_entropy_bottleneck_forward(cin):
+    sd = om.perturb_state(om.make_factorized_state(cin, 1), seed=cin)
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 1)
+    net.load_state_dict(sd)
+    eb = net.entropy_bottleneck.to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    y = 6 * torch.randn(3, 192, 8, 8, generator=g)
+    y[0, 0, 0, :4] = torch.tensor([0.5, 1.5, 2.5, -0.5]) + sd["entropy_bottleneck.quantiles"][0, 0, 1]  # ties
+    for form in ("plain", "signflip"):
+        eb.likelihood_form = form
+        ref_hat, ref_lik = om.eb_forward(y, sd, form=form)
+        s = torch.zeros(3, device=DEV, dtype=torch.float64)
+        out_hat, out_lik = eb(y.to(DEV), sum_log2=s)
+        assert torch.equal(out_hat.cpu(), ref_hat)  # round-half-even, exact
+        d = (out_lik.cpu() - ref_lik).abs()
+        assert bool((d <= 1e-5 * ref_lik + 3e-7).all()), float(d.max())
+        ref_s = torch.log2(ref_lik.double()).sum(dim=(1, 2, 3))
+        assert torch.allclose(s.cpu(), ref_s, rtol=1e-5)
+    # training mode with explicit noise
+    nz = torch.rand(3, 192, 8, 8, generator=g) - 0.5
+    eb.likelihood_form = "plain"
+    ref_hat, ref_lik = om.eb_forward(y, sd, training=True, noise=nz)
+    out_hat, out_lik = eb(y.to(DEV), training=True, noise=nz.to(DEV))
+    assert torch.equal(out_hat.cpu(), ref_hat)
+    assert bool(((out_lik.cpu() - ref_lik).abs() <= 1e-5 * ref_lik + 3e-7).all())
+
+
+def test_rans_kat_bytes_and_roundtrip(golden_dir):
+    g = np.load(os.path.join(golden_dir, "coder_kat.npz"))
+    n = g["sym"].size
+    # 5 streams: the KAT stream, its reverse, all-zero, all-escape, short
+    streams = [g["sym"], g["sym"][::-1].copy(), np.zeros(n, np.int32), np.full(n, 1000, np.int32),
+               np.concatenate([g["sym"][:7], np.zeros(n - 7, np.int32)])]
+    b = len(streams)
+    sym = torch.from_numpy(np.stack(streams, axis=1).astype(np.int32)).to(DEV)  # [n][b]
+    idx = torch.from_numpy(np.repeat(g["idx"][:, None], b, axis=1).astype(np.int32).copy()).to(DEV)
+    cdf = torch.from_numpy(g["cdfs"]).to(DEV)
+    cl = torch.from_numpy(g["cdf_len"]).to(DEV)
+    off = torch.from_numpy(g["offset"]).to(DEV)
+    table = torch.from_numpy(ops.rans_build_enc_table(g["cdfs"], g["cdf_len"])).to(DEV)
+    words, nwords, status = ops.rans_encode_batch(sym, 1, b, n, 0, cdf, cl, off, table, 2 * n + 8, b, indexes=idx)
+    assert int(status.item()) == 0
+    nw = nwords.cpu().numpy().astype(np.int64)
+    byte_off = np.concatenate([[0], np.cumsum(nw * 4)])
+    packed = ops.rans_compact(words, nwords, torch.from_numpy(byte_off).to(DEV), int(byte_off[-1])).cpu().numpy()
+    for i, s in enumerate(streams):
+        ref = rans.encode_with_indexes(s, g["idx"], g["cdfs"], g["cdf_len"], g["offset"])
+        assert packed[byte_off[i]:byte_off[i + 1]].tobytes() == ref, f"stream {i}"
+    assert packed[:byte_off[1]].tobytes() == g["data"].tobytes()
+    out = torch.empty_like(sym)
+    st = ops.rans_decode_batch(torch.from_numpy(packed).to(DEV), torch.from_numpy(byte_off).to(DEV), 1, b, n, 0, cdf,
+                               cl, off, out, b, indexes=idx)
+    assert int(st.item()) == 0
+    assert torch.equal(out, sym)
+    # overflow of the scratch capacity is reported, not silently truncated
+    _, _, status = ops.rans_encode_batch(sym, 1, b, n, 0, cdf, cl, off, table, 16, b, indexes=idx)
+    assert int(status.item()) == 1
+
+
+def test_rans_decoder_chained_bypass_count():
+    cdfs = np.array([[0, 40000, 65536]], dtype=np.int32)
+    items = [(0, 40000, False), (40000, 25536, False), (15, 0, True), (2, 0, True)] + [(0, 0, True)] * 17 + [(0, 40000, False)]
+    x, words = 1 << 31, []
+    for start, rng, byp in reversed(items):
+        freq = (1 << 12) if byp else rng
+        if x >= ((1 << 31 >> 16) << 32) * freq:
+            words.append(x & 0xFFFFFFFF)
+            x >>= 32
+        x = ((x << 4) | start) if byp else ((x // rng) << 16) + (x % rng) + start
+    words += [x >> 32, x & 0xFFFFFFFF]
+    data = np.frombuffer(b"".join(int(w).to_bytes(4, "little") for w in reversed(words)), dtype=np.uint8).copy()
+    out = torch.empty((3, 1), dtype=torch.int32, device=DEV)
+    st = ops.rans_decode_batch(torch.from_numpy(data).to(DEV), torch.tensor([0, data.size], device=DEV), 1, 1, 3, 3,
+                               torch.from_numpy(cdfs).to(DEV), torch.tensor([3], dtype=torch.int32, device=DEV),
+                               torch.tensor([0], dtype=torch.int32, device=DEV), out, 1)
+    assert int(st.item()) == 0 and out.flatten().tolist() == [0, 1, 0]
+
+
+def _load(cin, sd, precision="fp32", form="plain"):
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 1)
+    net.load_state_dict(sd)
+    net.entropy_bottleneck.likelihood_form = form
+    net = net.to(DEV).eval()
+    net.update(force=True)
+    return net.set_precision(precision)
+
+
+@pytest.mark.parametrize("name", ["factorized_c3_64", "factorized_c1_64", "factorized_c13_64",
+                                  "factorized_c3_64_signflip"])
+def test_model_golden_fp32(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cin, form = int(g["in_channels"]), str(g["form"])
+    sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=7)
+    chk = float(sum(v.double().abs().sum() for k, v in sorted(sd.items()) if v.dtype.is_floating_point))
+    if abs(chk - float(g["state_checksum"])) > 1e-6 * abs(chk):
+        pytest.skip("torch RNG stream differs from the one the fixture was made with")
+    net = _load(cin, sd, form=form)
+    assert np.array_equal(net.entropy_bottleneck._quantized_cdf.cpu().numpy(), g["cdf"])
+    x = torch.from_numpy(g["x_u8"].astype(np.float32) / 255.0).to(DEV)
+    with torch.no_grad():
+        y = net.g_a(x)
+        out = net(x)
+        comp = net.compress(x)
+        dec = net.decompress(comp["strings"], comp["shape"])
+    assert rel_err(y, torch.from_numpy(g["y"])) < 1e-5
+    sym = net.entropy_bottleneck._symbols_interleaved(y)  # [n][B]
+    assert np.array_equal(sym.cpu().numpy().T.reshape(g["symbols"].shape), g["symbols"])
+    lik, ref = out["likelihoods"]["y"].cpu(), torch.from_numpy(g["lik"])
+    assert bool(((lik - ref).abs() <= 1e-5 * ref + 3e-7).all())
+    assert rel_err(out["x_hat"], torch.from_numpy(g["x_hat"])) < 1e-5
+    assert comp["strings"][0][0] == g["string0"].tobytes()
+    assert comp["strings"][0][1] == g["string1"].tobytes()
+    assert tuple(comp["shape"]) == (int(g["size"]) // 16,) * 2
+    assert rel_err(dec["x_hat"], torch.from_numpy(g["x_dec"])) < 1e-5
+    bpp = licos_amd.metrics.compute_bpp(out)
+    assert abs(bpp - float(g["bpp"])) < 1e-5 * float(g["bpp"])
+    psnr = licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x)
+    assert abs(psnr - float(g["psnr"])) < 1e-4
+
+
+@pytest.mark.parametrize("cin,kind", [(3, "aid"), (13, "s2-merged")])
+def test_full_size_tiles_fp32_vs_oracle(cin, kind):
+    """256x256 tiles (BASELINE config sizes) against the oracle run on the host."""
+    sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=11)
+    net = _load(cin, sd)
+    om.eb_update(sd)
+    x = om.synthetic_tiles(2, cin, 256, seed=3, kind=kind)
+    with torch.no_grad():
+        out = net(x.to(DEV))
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+    ref = om.forward(x, sd)
+    ref_c = om.compress(x, sd)
+    assert rel_err(out["x_hat"], ref["x_hat"]) < 1e-5
+    lik, rl = out["likelihoods"]["y"].cpu(), ref["likelihoods"]["y"]
+    assert bool(((lik - rl).abs() <= 1e-5 * rl + 3e-7).all())
+    assert comp["strings"][0] == ref_c["strings"][0]
+    ref_d = om.decompress(ref_c["strings"], ref_c["shape"], sd)
+    assert rel_err(dec["x_hat"], ref_d["x_hat"]) < 1e-5
+    # size-independent property: decode(encode(x)) reproduces forward()'s clamped reconstruction
+    assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
+
+
+def test_ragged_and_empty_inputs():
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=2)
+    net = _load(3, sd)
+    om.eb_update(sd)
+    x = om.synthetic_tiles(1, 3, 256, seed=9)[:, :, :80, :112].contiguous()  # non-square, multiple of 16
+    with torch.no_grad():
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+    assert comp["strings"][0] == om.compress(x, sd)["strings"][0]
+    assert tuple(dec["x_hat"].shape) == (1, 3, 80, 112)
+    with pytest.raises(ValueError):
+        net.decompress([[b"\x00" * 6]], (5, 7))  # not a whole number of words
+    with pytest.raises(ValueError):
+        net.decompress([[b"\x00" * 8]], (5, 7))  # stream ends early

@@ -1,0 +1,162 @@
+"""CPU: the C-ABI library loads and exports every declared symbol, its host-side entry points
+agree with the oracle, and the host mirror of the reference interface behaves like it."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import licos_amd
+from licos_amd import _lib, ops
+from oracle import model as om
+from oracle import rans
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "licos_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(licos_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/licos_hip.h but not exported"
+    # and the Python binding table covers them all
+    assert set(names) == set(_lib.SIGNATURES.keys())
+    assert _lib.load().licos_abi_version() == 1
+
+
+def test_cpu_tensors_fail_loudly():
+    x = torch.zeros(1, 3, 16, 16)
+    w = torch.zeros(4, 3, 5, 5)
+    with pytest.raises(_lib.LicosError):
+        ops.conv2d_f32(x, w, None, 2, 2)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    with pytest.raises(_lib.LicosError):
+        net(torch.zeros(1, 3, 64, 64))
+
+
+def test_pmf_to_quantized_cdf_matches_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pmf_kat.npz"))
+    for i in range(int(g["n"])):
+        assert np.array_equal(ops.pmf_to_quantized_cdf(g[f"pmf{i}"], 16), g[f"cdf{i}"])
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(2, 120))
+        p = rng.random(n).astype(np.float32) ** float(rng.integers(1, 9))
+        p /= p.sum()
+        assert np.array_equal(ops.pmf_to_quantized_cdf(p, 16), rans.pmf_to_quantized_cdf(p, 16))
+    for bad in ([0.5, -0.1], [0.5, float("nan")], [0.0, 0.0]):
+        with pytest.raises(ValueError):
+            ops.pmf_to_quantized_cdf(np.array(bad, dtype=np.float32))
+
+
+def test_encoder_reciprocal_table_is_exact():
+    """q = mulhi64(x, rcp) >> shift must equal x // freq over the whole state range the coder
+    uses (x < freq << 47) and x + bias + q*(65536-freq) must equal the textbook update."""
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=1)
+    om.eb_update(sd)
+    cdf = sd["entropy_bottleneck._quantized_cdf"].numpy()
+    ln = sd["entropy_bottleneck._cdf_length"].numpy()
+    # add rows with freq 1, a power of two, 65535 and the single-symbol 65536 case
+    extra = np.zeros((2, cdf.shape[1]), dtype=np.int32)
+    extra[0, :5] = [0, 1, 2, 32770, 65536]
+    extra[1, :2] = [0, 65536]
+    cdf = np.concatenate([cdf, extra])
+    ln = np.concatenate([ln, np.array([5, 2], dtype=np.int32)])
+    table = ops.rans_build_enc_table(cdf, ln)
+    rng = np.random.default_rng(0)
+    rows = list(range(0, 192, 37)) + [192, 193]
+    for r in rows:
+        for s in range(ln[r] - 1):
+            rec = table[r, s].tobytes()
+            rcp = int.from_bytes(rec[0:8], "little")
+            bias = int.from_bytes(rec[8:12], "little")
+            freq16 = int.from_bytes(rec[12:14], "little")
+            shift = int.from_bytes(rec[14:16], "little")
+            start, freq = int(cdf[r, s]), int(cdf[r, s + 1] - cdf[r, s])
+            assert (freq16 or 65536) == freq
+            hi = freq << 47
+            xs = [1 << 31, (1 << 31) + 1, hi - 1, hi // 2, freq * 12345 + 1] + [int(v) for v in rng.integers(1 << 31, hi, size=64, dtype=np.uint64)]
+            for x in xs:
+                q = ((x * rcp) >> 64) >> shift
+                new = x + bias + q * (65536 - freq)
+                assert new == ((x // freq) << 16) + (x % freq) + start, (r, s, x)
+
+
+def test_state_dict_surface_and_channel_surgery():
+    net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1)
+    assert isinstance(net.g_a[0], torch.nn.Conv2d) and net.g_a[0].in_channels == 13
+    assert isinstance(net.g_s[6], torch.nn.ConvTranspose2d) and net.g_s[6].out_channels == 13
+    assert net.entropy_bottleneck.filters == (13, 13, 3, 3) and net.entropy_bottleneck.channels == 192
+    assert sum(p.numel() for p in net.parameters()) == 3108237
+    keys = set(net.state_dict().keys())
+    ref = set(om.make_factorized_state(13, 1).keys())
+    assert keys == ref
+    with pytest.raises(ValueError):
+        # a zoo model outside the three raw-data ones
+        from licos_amd import zoo
+        zoo.image_models["dummy"] = zoo.bmshj2018_factorized
+        try:
+            licos_amd.get_model("dummy", False, 1, 1)
+        finally:
+            del zoo.image_models["dummy"]
+    q6 = licos_amd.image_models["bmshj2018-factorized"](quality=6, pretrained=False)
+    assert q6.g_a[0].out_channels == 192 and q6.g_a[6].out_channels == 320
+
+
+def test_load_state_dict_accepts_both_eb_namings_and_updated_tables():
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=5)
+    om.eb_update(sd)
+    old = {}
+    for k, v in sd.items():
+        m = re.match(r"entropy_bottleneck\.(matrices|biases|factors)\.(\d+)", k)
+        if m:
+            k = "entropy_bottleneck._" + {"matrices": "matrix", "biases": "bias", "factors": "factor"}[m.group(1)] + m.group(2)
+        old[k] = v
+    for variant in (sd, old):
+        net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+        net.load_state_dict(variant)
+        assert tuple(net.entropy_bottleneck._quantized_cdf.shape) == tuple(sd["entropy_bottleneck._quantized_cdf"].shape)
+        for k, v in net.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+
+
+def test_update_builds_the_oracles_tables():
+    for cin, seed in ((3, 7), (1, 8), (13, 9)):
+        sd = om.perturb_state(om.make_factorized_state(cin, 1), seed=seed)
+        net = licos_amd.get_model("bmshj2018-factorized", False, cin, 1)
+        net.load_state_dict(sd)
+        assert net.update() is True and net.update() is False and net.update(force=True) is True
+        om.eb_update(sd)
+        for k in ("_quantized_cdf", "_cdf_length", "_offset"):
+            assert torch.equal(getattr(net.entropy_bottleneck, k).cpu(), sd["entropy_bottleneck." + k]), k
+        assert abs(float(net.aux_loss()) - float(om.eb_aux_loss(sd))) < 1e-3
+
+
+def test_compress_before_update_raises_like_compressai():
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    with pytest.raises(ValueError, match="Uninitialized CDFs"):
+        net.entropy_bottleneck.compress(torch.zeros(1, 192, 4, 4))
+
+
+def test_aux_optimizer_split_and_loss_surface():
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    conf = {"net": {"type": "Adam", "lr": 1e-4}, "aux": {"type": "Adam", "lr": 1e-3}}
+    opt = licos_amd.net_aux_optimizer(net, conf)
+    aux = [p for g in opt["aux"].param_groups for p in g["params"]]
+    assert len(aux) == 1 and aux[0] is net.entropy_bottleneck.quantiles
+    crit = licos_amd.RateDistortionLoss(lmbda=1e-2)
+    x = torch.rand(2, 3, 32, 32)
+    out = {"x_hat": x + 0.01, "likelihoods": {"y": torch.full((2, 192, 2, 2), 0.5)}}
+    res = crit(out, x)
+    ref = om.rate_distortion_loss(out, x, 1e-2)
+    for k in ("loss", "mse_loss", "bpp_loss"):
+        assert abs(float(res[k]) - float(ref[k])) < 1e-6

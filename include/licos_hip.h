@@ -149,6 +149,40 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/
                             int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int32_t *symbols,
                             int32_t *status, int B, void *stream);
 
+/* ----------------------------------------------- 16-bit MFMA path (gfx950)
+ * The fused hot path: 5x5 stride-2 Conv2d (+GDN) and ConvTranspose2d (+IGDN)
+ * stages of CompressAI models/google.py FactorizedPrior.g_a / g_s
+ * (instantiated at licos/model_utils.py:19, run at licos/train.py:190 and
+ * eval_utils.py:200-201) as LDS-tiled implicit GEMMs on v_mfma_f32_32x32x16_f16
+ * with the GDN normalisation as a second (bf16) MFMA GEMM in the epilogue.
+ *
+ * Packed operands (device, produced once per weight version):
+ *   conv weights  : licos_pack_conv_w_f16   [Cin16][25][Cout/32] MFMA A-fragments
+ *   deconv weights: licos_pack_deconv_w_f16 same, taps regrouped per output phase
+ *   GDN           : licos_pack_gdn_bf16     reparametrised gamma as bf16 A-fragments (k-permuted
+ *                                           for accumulator-as-operand use) + fp32 beta            */
+size_t licos_packed_conv_w_bytes(int Cin, int Cout);
+int licos_pack_conv_w_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_pack_deconv_w_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+size_t licos_packed_gdn_bytes(int C);
+int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
+                        float pedestal, int C, void *packed, void *stream);
+/* NCHW fp32 -> blk16 fp16 (channels zero-padded to a multiple of 16) */
+int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
+int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream);
+
+#define LICOS_EPI_NONE 0
+#define LICOS_EPI_GDN 1
+#define LICOS_EPI_IGDN 2
+/* x: blk16 [B][Cin16/16][H][W][16]; out: blk16 fp16 (y_blk16) or NCHW fp32 (y_nchw), exactly one non-NULL.
+ * Cout_real <= Cout_packed: channels beyond Cout_real are not stored.  H, W are the INPUT size. */
+int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
+                        int epilogue, void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout,
+                        void *stream);
+int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
+                          int epilogue, void *y_blk16, float *y_nchw, int clamp01, int B, int Cin, int H, int W,
+                          int Cout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+// 16-bit MFMA path (gfx950): 5x5 stride-2 Conv2d (+GDN) and ConvTranspose2d (+IGDN) as LDS-tiled
+// implicit GEMMs on v_mfma_f32_32x32x16_f16, fp32 accumulate.
+//
+// Orientation: D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel], k = (cin chunk of 16, tap, cin in
+// chunk).  Weights are the MFMA A operand, activations the B operand, so an accumulator tile holds
+// 32 output channels (registers) x 32 pixels (lanes).  That is the orientation in which
+//   * the GDN norm  beta_i + sum_j gamma[i][j] x_j^2  is a second MFMA GEMM that takes the squared
+//     accumulator tile as its B operand with no lane movement (MI355X guide, "accumulator tile as
+//     the next MFMA's operand"): gamma is pre-packed k-permuted to match;
+//   * a lane stores 4 consecutive channels of one pixel (8 B) into the blk16 layout.
+//
+// Activations between stages: blk16 = [B][C/16][H][W][16] fp16 (32 B per pixel per 16-channel chunk).
+// A workgroup (4 waves) owns 256 (NT=2) or 128 (NT=1) output pixels x all output channels; wave w
+// owns NT pixel-tiles of 32.  The K loop walks cin chunks; per chunk the input patch (with halo)
+// sits in LDS as 16-B granules [half][row][x-parity][x/2] (conv) or [half][row][x] (deconv) so
+// that the 32 lanes of a B-fragment read (consecutive output x) hit consecutive granules:
+// conflict-free ds_read_b128.  Weight slabs (one kernel row of 5 taps for conv, the taps of one
+// output phase for deconv) are staged in LDS in fragment order and shared by the 4 waves.
+#pragma once
+#include "common.hpp"
+
+namespace licos {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EPI_NONE = LICOS_EPI_NONE, EPI_GDN = LICOS_EPI_GDN, EPI_IGDN = LICOS_EPI_IGDN;
+
+__host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- geometry shared by host and device ---------------------------------------------------------
+template <int TH, int TW>
+struct ConvGeom {  // stride-2 5x5 conv: output tile TH x TW, input patch (2TH+3) x (2TW+3)
+  static constexpr int PH = 2 * TH + 3;
+  static constexpr int PW = 2 * TW + 3;
+  static constexpr int PWH = round_up(TW + 2, 4);  // granules per (row, parity); %4 keeps 16-wide tiles conflict-free
+  static constexpr int HALF = PH * 2 * PWH;        // granules per 8-channel half
+  static constexpr int PATCH_BYTES = 2 * HALF * 16;
+};
+template <int TH, int TW>
+struct DeconvGeom {  // one output phase of a stride-2 5x5 transposed conv: input tile TH x TW, patch (TH+2) x (TW+2)
+  static constexpr int PH = TH + 2;
+  static constexpr int PW = TW + 2;
+  static constexpr int RS = (TW == 16) ? 32 : round_up(TW + 2, 4);  // row stride in granules
+  static constexpr int HALF = PH * RS;
+  static constexpr int PATCH_BYTES = 2 * HALF * 16;
+};
+
+struct MfmaArgs {
+  const _Float16 *x;      // blk16 input
+  const half8 *wp;        // packed weights (A fragments)
+  const float *bias;      // [32*MT] fp32 (zero padded)
+  const bf16x8 *gamma;    // packed gamma fragments [it][jt][s][lane]
+  const float *beta;      // [32*MT]
+  _Float16 *y_blk;        // blk16 output (or null)
+  float *y_nchw;          // NCHW fp32 output (or null)
+  int B, Cin16, H, W;     // input geometry
+  int Ho, Wo, Cout;       // output geometry; Cout = real channel count (<= 32*MT)
+  int tiles_x, tiles_y;
+  int clamp01;
+};
+
+// ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
+template <int MT, int NT, int EPI>
+__device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, int b, const int (&oy)[NT],
+                                      const int (&ox)[NT], int lane) {
+  const int h = lane >> 5;
+  // bias: channel of register q in tile mt is 32mt + (q&3) + 8(q>>2) + 4h
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bv = *reinterpret_cast<const float4 *>(a.bias + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt][4 * g + 0] += bv.x;
+        acc[mt][nt][4 * g + 1] += bv.y;
+        acc[mt][nt][4 * g + 2] += bv.z;
+        acc[mt][nt][4 * g + 3] += bv.w;
+      }
+    }
+  }
+  const int Cout16 = (a.Cout + 15) >> 4;
+#pragma unroll
+  for (int it = 0; it < MT; ++it) {
+    f32x16 scale[NT];
+    if (EPI != EPI_NONE) {
+      // norm tile `it` = beta + sum_jt sum_s gamma(it, jt, s) x sq(acc[jt], regs 8s..8s+7)
+      f32x16 norm[NT];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(a.beta + 32 * it + 8 * g + 4 * h);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          norm[nt][4 * g + 0] = bv.x;
+          norm[nt][4 * g + 1] = bv.y;
+          norm[nt][4 * g + 2] = bv.z;
+          norm[nt][4 * g + 3] = bv.w;
+        }
+      }
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 gfrag = a.gamma[((it * MT + jt) * 2 + s) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 sq;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = acc[jt][nt][8 * s + e];
+              sq[e] = (__bf16)(v * v);
+            }
+            norm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfrag, sq, norm[nt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          scale[nt][q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[nt][q]) : __builtin_amdgcn_sqrtf(norm[nt][q]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool live = oy[nt] < a.Ho && ox[nt] < a.Wo && oy[nt] >= 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[it][nt][4 * g + e];
+          if (EPI != EPI_NONE) v[e] *= scale[nt][4 * g + e];
+          if (a.clamp01) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+        }
+        const int c0 = 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
+        if (!live) continue;
+        if (a.y_blk) {
+          if (c0 < Cout16 * 16) {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (c0 + e < a.Cout) ? (_Float16)v[e] : (_Float16)0.f;
+            _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + (c0 >> 4)) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + (c0 & 15);
+            *reinterpret_cast<half4 *>(dst) = o;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < a.Cout) a.y_nchw[(((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt]] = v[e];
+        }
+      }
+    }
+  }
+}
+
+
+static inline int mt_for(int Cout) {
+  if (Cout <= 32) return 1;
+  if (Cout <= 128) return 4;
+  if (Cout <= 192) return 6;
+  return 0;
+}
+
+// defined in mfma_conv.hip / mfma_deconv.hip
+int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
+int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
+
+}  // namespace licos

@@ -1,0 +1,231 @@
+// MFMA path: operand packing, layout conversion and the C entry points.
+#include "mfma_common.hpp"
+
+namespace licos {
+
+// ---- packing kernels -----------------------------------------------------------------------------------
+// conv weights [Cout][Cin][5][5] fp32 -> [cc][ky][kx][mt][lane][8] fp16 A-fragments
+__global__ void pack_conv_w_kernel(const float *__restrict__ w, int Cin, int Cout, int Cin16, int MT,
+                                   _Float16 *__restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int mt = (int)(rest % MT); rest /= MT;
+    const int tap = (int)(rest % 25); rest /= 25;
+    const int cc = (int)rest;
+    const int co = 32 * mt + (lane & 31), ci = 16 * cc + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 25 + tap];
+    out[e] = (_Float16)v;
+  }
+}
+
+// deconv weights [Cin][Cout][5][5] fp32 -> [phase][cc][tap in phase][mt][lane][8]
+__global__ void pack_deconv_w_kernel(const float *__restrict__ w, int Cin, int Cout, int Cin16, int MT,
+                                     _Float16 *__restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int mt = (int)(rest % MT); rest /= MT;
+    // rest = phase_tap0 * Cin16 + cc * ntap + t
+    int phase = 0, tap0 = 0;
+    const int ntaps[4] = {9, 6, 6, 4}, starts[4] = {0, 9, 15, 21};
+    for (int p = 3; p >= 0; --p)
+      if (rest >= (long)starts[p] * Cin16) { phase = p; tap0 = starts[p]; break; }
+    rest -= (long)tap0 * Cin16;
+    const int ntap = ntaps[phase];
+    const int cc = (int)(rest / ntap), t = (int)(rest % ntap);
+    const int py = phase >> 1, px = phase & 1, nkx = px ? 2 : 3;
+    const int ky = py + 2 * (t / nkx), kx = px + 2 * (t % nkx);
+    const int co = 32 * mt + (lane & 31), ci = 16 * cc + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)ci * Cout + co) * 25 + ky * 5 + kx];
+    out[e] = (_Float16)v;
+  }
+}
+
+// GDN: gamma_eff = max(gamma, bound)^2 - pedestal as bf16 A-fragments, k-permuted for the
+// accumulator-as-B-operand product: element e of lane (r, h) of fragment (it, jt, s) is
+// gamma[32it + r][32jt + 16s + 8(e>>2) + 4h + (e&3)].  beta_eff (fp32, padded) follows.
+__global__ void pack_gdn_kernel(const float *__restrict__ beta_raw, const float *__restrict__ gamma_raw,
+                                float beta_bound, float gamma_bound, float pedestal, int C, int MT,
+                                __bf16 *__restrict__ gout, float *__restrict__ bout) {
+  const long total = (long)MT * MT * 2 * 64 * 8;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int s = (int)(rest & 1); rest >>= 1;
+    const int jt = (int)(rest % MT), it = (int)(rest / MT);
+    const int i = 32 * it + (lane & 31), j = 32 * jt + 16 * s + 8 * (el >> 2) + 4 * (lane >> 5) + (el & 3);
+    float v = 0.f;
+    if (i < C && j < C) {
+      const float g = fmaxf(gamma_raw[(size_t)i * C + j], gamma_bound);
+      v = g * g - pedestal;
+    }
+    gout[e] = (__bf16)v;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * MT; i += gridDim.x * blockDim.x) {
+    float v = 1.f;  // padded channels: norm = 1 keeps rsqrt/sqrt finite
+    if (i < C) {
+      const float t = fmaxf(beta_raw[i], beta_bound);
+      v = t * t - pedestal;
+    }
+    bout[i] = v;
+  }
+}
+
+__global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int C16, long HW,
+                                     long total) {
+  // one thread per (b, chunk, pixel): writes 16 halfs (32 B)
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const int cc = (int)((e / HW) % C16);
+    const long b = e / (HW * C16);
+    half8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c0 = cc * 16 + j, c1 = c0 + 8;
+      lo[j] = (c0 < C) ? (_Float16)x[((size_t)b * C + c0) * HW + p] : (_Float16)0.f;
+      hi[j] = (c1 < C) ? (_Float16)x[((size_t)b * C + c1) * HW + p] : (_Float16)0.f;
+    }
+    half8 *dst = reinterpret_cast<half8 *>(y + (size_t)e * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
+__global__ void blk16_to_nchw_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, int C16, long HW,
+                                     long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const int c = (int)((e / HW) % C);
+    const long b = e / (HW * C);
+    y[e] = (float)x[(((size_t)b * C16 + (c >> 4)) * HW + p) * 16 + (c & 15)];
+  }
+}
+
+}  // namespace licos
+
+using namespace licos;
+
+extern "C" {
+
+size_t licos_packed_conv_w_bytes(int Cin, int Cout) {
+  const int MT = mt_for(Cout);
+  if (MT == 0 || Cin <= 0) return 0;
+  return (size_t)((Cin + 15) / 16) * 25 * MT * 1024;
+}
+
+int licos_pack_conv_w_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
+  const int MT = mt_for(Cout);
+  LICOS_REQUIRE(w && packed && Cin > 0 && MT > 0, "pack_conv_w_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  const int Cin16 = (Cin + 15) / 16;
+  const long total = (long)Cin16 * 25 * MT * 512;
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                     as_stream(stream), w, Cin, Cout, Cin16, MT, static_cast<_Float16 *>(packed), total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_pack_deconv_w_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
+  const int MT = mt_for(Cout);
+  LICOS_REQUIRE(w && packed && Cin > 0 && MT > 0, "pack_deconv_w_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  const int Cin16 = (Cin + 15) / 16;
+  const long total = (long)Cin16 * 25 * MT * 512;
+  hipLaunchKernelGGL(pack_deconv_w_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                     as_stream(stream), w, Cin, Cout, Cin16, MT, static_cast<_Float16 *>(packed), total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+size_t licos_packed_gdn_bytes(int C) {
+  const int MT = mt_for(C);
+  if (MT == 0) return 0;
+  return (size_t)MT * MT * 2 * 1024 + (size_t)32 * MT * sizeof(float);
+}
+
+int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
+                        float pedestal, int C, void *packed, void *stream) {
+  const int MT = mt_for(C);
+  LICOS_REQUIRE(beta_raw && gamma_raw && packed && MT > 0, "pack_gdn_bf16: unsupported C=%d", C);
+  __bf16 *g = static_cast<__bf16 *>(packed);
+  float *bta = reinterpret_cast<float *>(static_cast<unsigned char *>(packed) + (size_t)MT * MT * 2 * 1024);
+  hipLaunchKernelGGL(pack_gdn_kernel, dim3(64), dim3(256), 0, as_stream(stream), beta_raw, gamma_raw, beta_bound,
+                     gamma_bound, pedestal, C, MT, g, bta);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
+  LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_blk16: bad arguments");
+  const int C16 = (C + 15) / 16;
+  const long HW = (long)H * W, total = (long)B * C16 * HW;
+  hipLaunchKernelGGL(nchw_to_blk16_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,
+                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), C, C16, HW, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream) {
+  LICOS_REQUIRE(x_blk16 && y && B > 0 && C > 0 && H > 0 && W > 0, "blk16_to_nchw_f32: bad arguments");
+  const int C16 = (C + 15) / 16;
+  const long HW = (long)H * W, total = (long)B * C * HW;
+  hipLaunchKernelGGL(blk16_to_nchw_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,
+                     as_stream(stream), static_cast<const _Float16 *>(x_blk16), y, C, C16, HW, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bias, const void *gdn, int epi,
+                     void *y_blk, float *y_nchw, int B, int Cin, int H, int W, int Cout, int *MT_out, const char *who) {
+  LICOS_REQUIRE(x && wp && bias, "%s: NULL buffer", who);
+  LICOS_REQUIRE((y_blk != nullptr) != (y_nchw != nullptr), "%s: exactly one of y_blk16 / y_nchw must be given", who);
+  LICOS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0, "%s: bad shape", who);
+  const int MT = mt_for(Cout);
+  LICOS_REQUIRE(MT > 0 && Cout > 0, "%s: Cout=%d unsupported (max 192)", who, Cout);
+  LICOS_REQUIRE(epi == EPI_NONE || gdn, "%s: (I)GDN epilogue needs packed gamma/beta", who);
+  LICOS_REQUIRE(epi >= 0 && epi <= 2, "%s: bad epilogue %d", who, epi);
+  LICOS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)bias & 15) == 0, "%s: buffers must be 16-byte aligned", who);
+  a.x = static_cast<const _Float16 *>(x);
+  a.wp = static_cast<const half8 *>(wp);
+  a.bias = bias;
+  a.gamma = static_cast<const bf16x8 *>(gdn);
+  a.beta = gdn ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(gdn) + (size_t)MT * MT * 2 * 1024) : nullptr;
+  a.y_blk = static_cast<_Float16 *>(y_blk);
+  a.y_nchw = y_nchw;
+  a.B = B;
+  a.Cin16 = (Cin + 15) / 16;
+  a.H = H;
+  a.W = W;
+  a.Cout = Cout;
+  a.clamp01 = 0;
+  *MT_out = MT;
+  return LICOS_OK;
+}
+
+int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
+                        int epilogue, void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout,
+                        void *stream) {
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_blk16, w_packed, bias, gdn_packed, epilogue, y_blk16, y_nchw, B, Cin, H, W, Cout, &MT, "conv5x5s2_f16");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = (H - 1) / 2 + 1;
+  a.Wo = (W - 1) / 2 + 1;
+  return mfma_dispatch_conv(a, MT, epilogue, a.Wo, as_stream(stream));
+}
+
+int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
+                          int epilogue, void *y_blk16, float *y_nchw, int clamp01, int B, int Cin, int H, int W,
+                          int Cout, void *stream) {
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_blk16, w_packed, bias, gdn_packed, epilogue, y_blk16, y_nchw, B, Cin, H, W, Cout, &MT, "deconv5x5s2_f16");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = 2 * H;
+  a.Wo = 2 * W;
+  a.clamp01 = clamp01;
+  return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""Host-side driver of the fused 16-bit MFMA pipeline.
+
+A transform (``g_a`` / ``g_s``) is a chain of (conv | deconv)[+ GDN] stages.  Each stage is one
+HIP kernel (licos_amd/csrc/mfma_{conv,deconv}.hip) reading and writing the blk16 fp16 layout; only
+the two ends of the chain touch NCHW fp32.  Packed operands (MFMA weight fragments, padded bias,
+reparametrised bf16 gamma fragments) are cached per module and rebuilt when a parameter's
+version or storage changes - so modules swapped in after construction (model_utils.py:31-45) and
+optimiser steps are picked up lazily.
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import GDN, conv_geometry
+
+_cache = weakref.WeakKeyDictionary()
+
+
+def _pver(p):
+    return None if p is None else (p.data_ptr(), p._version, str(p.device))
+
+
+def _packed_conv(m):
+    key = (_pver(m.weight), _pver(m.bias))
+    ent = _cache.get(m)
+    if ent is None or ent[0] != key:
+        transposed = isinstance(m, nn.ConvTranspose2d)
+        geo = conv_geometry(m)
+        if geo[:3] != (5, 2, 2) or (transposed and geo[3] != 1):
+            raise ValueError("licos_amd: the fp16 MFMA path implements kernel 5 / stride 2 / padding 2 "
+                             "(output_padding 1) stages only; use precision='fp32' for other shapes")
+        cout = m.out_channels
+        wp = ops.pack_conv_w_f16(m.weight.detach(), transposed=transposed)
+        bp = ops.pad_bias(m.bias, cout, m.weight.device)
+        ent = (key, wp, bp)
+        _cache[m] = ent
+    return ent[1], ent[2]
+
+
+def _packed_gdn(m):
+    key = (_pver(m.beta), _pver(m.gamma))
+    ent = _cache.get(m)
+    if ent is None or ent[0] != key:
+        bb, gb, ped = m.reparam_args()
+        ent = (key, ops.pack_gdn_bf16(m.beta.detach(), m.gamma.detach(), bb, gb, ped))
+        _cache[m] = ent
+    return ent[1]
+
+
+def stages(seq):
+    """[(conv module, gdn module or None)] for a transform chain; validates the pattern."""
+    mods = list(seq)
+    out = []
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            raise TypeError(f"licos_amd: fp16 path expects conv/deconv stages, found {type(m).__name__}")
+        g = None
+        if i + 1 < len(mods) and isinstance(mods[i + 1], GDN):
+            g = mods[i + 1]
+            if g.in_channels != m.out_channels:
+                raise ValueError("licos_amd: GDN width does not match the preceding conv")
+            i += 1
+        elif i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Conv2d, nn.ConvTranspose2d)):
+            raise TypeError(f"licos_amd: fp16 path does not fuse {type(mods[i + 1]).__name__}; use precision='fp32'")
+        out.append((m, g))
+        i += 1
+    return out
+
+
+def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False):
+    """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32."""
+    st = stages(seq)
+    if x_blk is None:
+        if x.dtype != torch.float32:
+            raise ValueError("licos_amd: inputs must be float32")
+        if x.shape[1] != st[0][0].in_channels:
+            raise ValueError(f"expected {st[0][0].in_channels} input channels, got {x.shape[1]}")
+        cur = ops.nchw_f32_to_blk16(x.contiguous())
+    else:
+        cur = x_blk
+    for idx, (m, g) in enumerate(st):
+        last = idx == len(st) - 1
+        wp, bp = _packed_conv(m)
+        gp = _packed_gdn(g) if g is not None else None
+        if isinstance(m, nn.ConvTranspose2d):
+            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
+            cur = ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, out_nchw=last,
+                                      clamp01=clamp01 and last)
+        else:
+            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
+            cur = ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, out_nchw=last)
+    return cur

@@ -224,3 +224,109 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
                                              batch, _stream())
     _lib.check(rc, "rans_decode_batch")
     return status
+
+
+# ----------------------------------------------------------------------------- 16-bit MFMA path
+EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
+
+
+def mfma_tiles(cout):
+    """Number of 32-channel accumulator tiles the MFMA kernels use for `cout` output channels."""
+    if cout <= 32:
+        return 1
+    if cout <= 128:
+        return 4
+    if cout <= 192:
+        return 6
+    raise ValueError(f"licos_amd: the fp16 MFMA path supports at most 192 output channels, got {cout}")
+
+
+def pack_conv_w_f16(w, transposed=False):
+    """fp32 conv weight -> fp16 MFMA A-fragments (+ returns padded fp32 bias holder size)."""
+    _dev(w)
+    if transposed:
+        cin, cout = w.shape[:2]
+    else:
+        cout, cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (5, 5):
+        raise ValueError("licos_amd: the fp16 MFMA path implements 5x5 stride-2 stages only")
+    nbytes = _lib.load().licos_packed_conv_w_bytes(cin, cout)
+    if nbytes == 0:
+        raise ValueError(f"licos_amd: unsupported channel counts Cin={cin} Cout={cout} for the fp16 path")
+    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    fn = _lib.load().licos_pack_deconv_w_f16 if transposed else _lib.load().licos_pack_conv_w_f16
+    _lib.check(fn(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()), "pack_conv_w_f16")
+    return packed
+
+
+def pad_bias(bias, cout, device):
+    n = 32 * mfma_tiles(cout)
+    out = torch.zeros(n, device=device, dtype=torch.float32)
+    if bias is not None:
+        out[:cout] = bias.detach()
+    return out
+
+
+def pack_gdn_bf16(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
+    _dev(beta_raw, gamma_raw)
+    c = beta_raw.numel()
+    nbytes = _lib.load().licos_packed_gdn_bytes(c)
+    if nbytes == 0:
+        raise ValueError(f"licos_amd: GDN over {c} channels unsupported on the fp16 path")
+    packed = torch.empty(nbytes, device=beta_raw.device, dtype=torch.uint8)
+    rc = _lib.load().licos_pack_gdn_bf16(_p(_f32(beta_raw)), _p(_f32(gamma_raw)), beta_bound, gamma_bound, pedestal, c,
+                                         _p(packed), _stream())
+    _lib.check(rc, "pack_gdn_bf16")
+    return packed
+
+
+def nchw_f32_to_blk16(x):
+    _dev(x)
+    b, c, h, w = x.shape
+    y = torch.empty((b, (c + 15) // 16, h, w, 16), device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_nchw_f32_to_blk16(_p(_f32(x)), _p(y), b, c, h, w, _stream()), "nchw_f32_to_blk16")
+    return y
+
+
+def blk16_to_nchw_f32(x, c):
+    _dev(x)
+    b, c16, h, w, _ = x.shape
+    y = torch.empty((b, c, h, w), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().licos_blk16_to_nchw_f32(_p(x), _p(y), b, c, h, w, _stream()), "blk16_to_nchw_f32")
+    return y
+
+
+def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False):
+    _dev(x_blk, w_packed, bias_padded, gdn_packed)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("conv5x5s2_f16: input is not the blk16 fp16 layout of `cin` channels")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out_nchw:
+        y = torch.empty((b, cout, ho, wo), device=x_blk.device, dtype=torch.float32)
+        yb, yn = None, y
+    else:
+        y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)
+        yb, yn = y, None
+    rc = _lib.load().licos_conv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+                                         _p(yn), b, cin, h, w, cout, _stream())
+    _lib.check(rc, "conv5x5s2_f16")
+    return y
+
+
+def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, clamp01=False):
+    _dev(x_blk, w_packed, bias_padded, gdn_packed)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("deconv5x5s2_f16: input is not the blk16 fp16 layout of `cin` channels")
+    ho, wo = 2 * h, 2 * w
+    if out_nchw:
+        y = torch.empty((b, cout, ho, wo), device=x_blk.device, dtype=torch.float32)
+        yb, yn = None, y
+    else:
+        y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)
+        yb, yn = y, None
+    rc = _lib.load().licos_deconv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+                                           _p(yn), int(clamp01), b, cin, h, w, cout, _stream())
+    _lib.check(rc, "deconv5x5s2_f16")
+    return y

@@ -1,0 +1,144 @@
+"""GPU tests of the 16-bit MFMA path.  Each stage is checked against torch-CPU convolution of the
+SAME fp16-rounded operands (so only accumulation order and the output rounding differ), the fused
+(I)GDN epilogue against the fp32 definition, and the whole model against the oracle on the
+quantities BASELINE.json names for the fp16 configuration: bpp, PSNR, symbol mismatch rate."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import licos_amd
+from licos_amd import engine, ops
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def h16(t):
+    return t.half().float()
+
+
+@pytest.mark.parametrize("c,h,w", [(3, 8, 8), (16, 5, 7), (13, 16, 16), (192, 4, 4), (130, 3, 5)])
+def test_blk16_layout_roundtrip(c, h, w):
+    g = torch.Generator().manual_seed(c)
+    x = h16(torch.randn(2, c, h, w, generator=g))
+    blk = ops.nchw_f32_to_blk16(x.to(DEV))
+    c16 = (c + 15) // 16
+    assert tuple(blk.shape) == (2, c16, h, w, 16)
+    ref = torch.zeros(2, c16 * 16, h, w)
+    ref[:, :c] = x
+    ref = ref.reshape(2, c16, 16, h, w).permute(0, 1, 3, 4, 2)
+    assert torch.equal(blk.cpu().float(), ref)
+    assert torch.equal(ops.blk16_to_nchw_f32(blk, c).cpu(), x)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(3, 128, 64, 64), (128, 128, 64, 64), (128, 128, 32, 32), (128, 192, 32, 32),
+                                           (13, 128, 40, 72), (128, 128, 22, 38), (1, 128, 16, 16), (128, 192, 64, 80)])
+def test_conv_stage_exact_operands(cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 5, 5, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride=2, padding=2)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    out = ops.conv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5
+    outb = ops.conv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=False)
+    assert rel_err(ops.blk16_to_nchw_f32(outb, cout), ref) < 1e-3  # fp16 output rounding
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
+                                           (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19)])
+def test_deconv_stage_exact_operands(cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cin, cout, 5, 5, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV), transposed=True)
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    out = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5
+    if cout > 32:
+        outb = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=False)
+        assert rel_err(ops.blk16_to_nchw_f32(outb, cout), ref) < 1e-3
+    outc = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True, clamp01=True)
+    assert rel_err(outc, ref.clamp(0, 1)) < 2e-5
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("h,w", [(64, 64), (32, 32)])
+def test_fused_gdn_epilogue(inverse, h, w):
+    c = 128
+    g = torch.Generator().manual_seed(h + inverse)
+    sd = {}
+    om._gdn_init(sd, "g.", c)
+    sd["g.gamma"] = sd["g.gamma"] + 0.03 * torch.rand(c, c, generator=g)
+    sd["g.beta"] = sd["g.beta"] * (0.5 + torch.rand(c, generator=g))
+    m = licos_amd.GDN(c, inverse=inverse)
+    m.load_state_dict({k[2:]: v for k, v in sd.items()})
+    m = m.to(DEV)
+    gp = engine._packed_gdn(m)
+    x = h16(torch.randn(2, c, h, w, generator=g))
+    wt = h16(torch.randn(c, c, 5, 5, generator=g) * 0.03)
+    b = torch.randn(c, generator=g)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), c, DEV)
+    epi = ops.EPI_IGDN if inverse else ops.EPI_GDN
+    if inverse:
+        pre = F.conv_transpose2d(x, wt.transpose(0, 1).contiguous(), b, stride=2, padding=2, output_padding=1)
+        wp = ops.pack_conv_w_f16(wt.transpose(0, 1).contiguous().to(DEV), transposed=True)
+        out = ops.deconv5x5s2_f16(xb, wp, bp, gp, epi, c, c)
+    else:
+        pre = F.conv2d(x, wt, b, stride=2, padding=2)
+        wp = ops.pack_conv_w_f16(wt.to(DEV))
+        out = ops.conv5x5s2_f16(xb, wp, bp, gp, epi, c, c)
+    ref = om.gdn(pre, sd, "g.", inverse=inverse)
+    err = rel_err(ops.blk16_to_nchw_f32(out, c), ref)
+    print(f"fused {'IGDN' if inverse else 'GDN'} rel err {err:.2e}")
+    assert err < 4e-3  # bf16 gamma / x^2 operands + fp16 output
+
+
+@pytest.mark.parametrize("cin,kind", [(3, "aid"), (1, "s2"), (13, "s2-merged")])
+def test_model_fp16_matches_oracle_rates(cin, kind):
+    sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=11, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    om.eb_update(sd)
+    x = om.synthetic_tiles(2, cin, 256, seed=4, kind=kind)
+    with torch.no_grad():
+        out = net(x.to(DEV))
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+        y16 = net.g_a(x.to(DEV))
+    ref = om.forward(x, sd)
+    y_err = rel_err(y16, ref["y"])
+    sym16 = torch.round(y16.cpu() - sd["entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1))
+    mism = float((sym16 != om.eb_symbols(ref["y"], sd)).float().mean())
+    bpp16, bpp = licos_amd.metrics.compute_bpp(out), om.compute_bpp(ref)
+    psnr16 = licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x.to(DEV))
+    psnr = om.compute_psnr(ref["x_hat"].clamp(0, 1), x)
+    nbytes16 = sum(len(s) for s in comp["strings"][0])
+    nbytes = sum(len(s) for s in om.compress(x, sd)["strings"][0])
+    print(f"cin={cin}: y rel err {y_err:.2e}, symbol mismatch {mism:.4f}, bpp {bpp16:.4f} vs {bpp:.4f}, "
+          f"PSNR {psnr16:.3f} vs {psnr:.3f} dB, bytes {nbytes16} vs {nbytes}")
+    assert y_err < 1e-2
+    assert mism < 0.05
+    assert abs(bpp16 - bpp) < 0.01 * bpp
+    assert abs(psnr16 - psnr) < 0.1
+    assert abs(nbytes16 - nbytes) < 0.01 * nbytes + 16
+    # self-consistency: the decoder reproduces forward()'s reconstruction from the bytes alone
+    assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6

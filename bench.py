@@ -1,0 +1,160 @@
+"""Headline benchmark: 256x256 tiles/s, encode + decode (BASELINE.json metric), on N MI355X.
+
+One step = compress(x) -> byte strings -> decompress(strings) for one batch of B synthetic
+3x256x256 tiles per GPU that are already resident in HBM (BASELINE.json configs[1]:
+bmshj2018_factorized q=3, 3 channels, fp16 MFMA path).  Tiles shard across ranks with no
+data-path collective (weak scaling: B tiles per GPU).  Rank 0 prints ONE JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TILE_A3 = 2 * 1677721600  # g_a[2]: 128->128 5x5 s2 at 128^2 -> 64^2
+PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16 MFMA (MI355X_MICROARCH.md chip table)
+
+
+def stage_flops(kind, cin, cout, h, w):
+    """Algorithmic FLOPs of one stage per tile (conv + fused GDN MACs x 2), input size h x w."""
+    pix_out = (h // 2) * (w // 2) if kind == "conv" else (2 * h) * (2 * w)
+    taps = 25 if kind == "conv" else 25 / 4.0
+    return 2.0 * pix_out * taps * cin * cout
+
+
+def cpu_baseline(sd, cin, batch, reps):
+    """The oracle (torch-CPU conv = the reference's CPU arithmetic; restated EB; C rANS) timed on
+    this host's cores on a bounded sample of the same workload."""
+    import torch
+    from oracle import model as om
+    threads = min(os.cpu_count() or 1, 16)  # the GPU box gives one GPU a 16-core share; more threads only thrash
+    torch.set_num_threads(threads)
+    x = om.synthetic_tiles(batch, cin, 256, seed=0)
+    om.compress(x[:2], sd)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c = om.compress(x, sd)
+        om.decompress(c["strings"], c["shape"], sd)
+    dt = time.perf_counter() - t0
+    return batch * reps / dt, dt, threads
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--quality", type=int, default=3)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import licos_amd
+    from licos_amd import _lib, engine, synthetic
+
+    _lib.load()  # the HIP library is the product: fail loudly if it is missing
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(42)
+    net = licos_amd.get_model("bmshj2018-factorized", False, args.channels, args.quality)
+    net = net.to(dev).eval().set_precision(args.precision)
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=0)
+    B = args.batch
+    x = synthetic.tiles(B, args.channels, 256, seed=100 + rank, device=dev)
+
+    def step():
+        with torch.no_grad():
+            comp = net.compress(x)
+            dec = net.decompress(comp["strings"], comp["shape"])
+        return comp, dec
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        comp, dec = step()
+    fence()
+    engine.stage_events = {} if args.precision == "fp16" else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        comp, dec = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    events, engine.stage_events = engine.stage_events, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # quality of what was just coded (bpp from the actual bytes; PSNR of the decoded tiles)
+    nbytes = sum(len(s) for s in comp["strings"][0])
+    bpp = nbytes * 8.0 / (B * 256 * 256)
+    psnr = licos_amd.metrics.compute_psnr(dec["x_hat"], x)
+
+    stages = {}
+    roof = None
+    if events:
+        for key, evs in events.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+            fl = stage_flops(*key) * B
+            stages["%s_%d_%d_%dx%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2)}
+        key = ("conv", 128, 128, 128, 128)
+        if key in events:
+            ms = sum(e0.elapsed_time(e1) for e0, e1 in events[key]) / len(events[key])
+            ach = FLOP_PER_TILE_A3 * B / (ms * 1e-3) / 1e12
+            roof = {"kernel": "conv5x5s2_mfma_kernel<4,2,8,32,GDN> (g_a[2], 128->128 @128^2->64^2)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+                    "launches": len(events[key]), "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * B}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        tps, dt, threads = cpu_baseline(sd, args.channels, 32, 8)
+        cpu = {"value": round(tps, 2), "unit": "tiles/s", "cores": threads, "kind": "port",
+               "sample": "oracle compress+decompress (torch-CPU conv, C rANS), 8 reps x 32 tiles of the same 3x256x256 "
+                         "workload, %.1f s, %d torch threads on a %d-core host" % (dt, threads, os.cpu_count() or 0)}
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "256x256 tiles/s encode+decode (bpp+PSNR matched)", "value": round(value, 1), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": "bmshj2018_factorized q=%d, %d-ch 256x256 tiles, compress()+decompress() through the "
+                                   "module API, %d tiles per GPU per step" % (args.quality, args.channels, B),
+                       "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": "synthetic trained-like (seeded)"},
+            "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
+            "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

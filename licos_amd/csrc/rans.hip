@@ -146,6 +146,170 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const uint8_t *__restri
   if (src.over) atomicOr(status, 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Plane-indexed fast path (indexes == NULL: the CDF row of position i is i / plane, i.e. the
+// EntropyBottleneck case).  One wave = 64 streams walking the same (channel, position) in lock-step,
+// so per channel the wave stages that row's table in LDS once and every per-symbol lookup is an LDS
+// read instead of a dependent global load; symbol loads are batched ahead of the serial chain, and
+// the decoder keeps the next two stream words in registers so renormalisation never waits on HBM.
+constexpr int SYM_BATCH = 8;
+
+__global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__restrict__ symbols, long ssb, long ssi,
+                                                               int C, int plane, int cdf_stride,
+                                                               const int32_t *__restrict__ cdf_len,
+                                                               const int32_t *__restrict__ offset,
+                                                               const EncRec *__restrict__ table,
+                                                               uint32_t *__restrict__ words, int cap_words,
+                                                               int32_t *__restrict__ nwords, int32_t *__restrict__ status,
+                                                               int B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  EncRec *s_tab = reinterpret_cast<EncRec *>(smem_raw);
+  const int lane = threadIdx.x;
+  const int b_raw = blockIdx.x * 64 + lane;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;  // idle lanes shadow the last stream (no stores)
+  WordSink sink{words, B, b, cap_words, false};
+  uint64_t x = RANS_L;
+  const int32_t *sp = symbols + (size_t)b * ssb;
+  for (int c = C - 1; c >= 0; --c) {
+    const int len = cdf_len[c];
+    const int32_t max_value = len - 2;
+    const int32_t off = offset[c];
+    __syncthreads();
+    for (int e = lane; e < len - 1; e += 64) s_tab[e] = table[(size_t)c * cdf_stride + e];
+    __syncthreads();
+    for (int p1 = plane; p1 > 0; p1 -= SYM_BATCH) {
+      const int nb = p1 < SYM_BATCH ? p1 : SYM_BATCH;
+      int32_t sv[SYM_BATCH];
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k)
+        if (k < nb) sv[k] = sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi];
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k) {
+        if (k >= nb) break;
+        int32_t value = sv[k] - off;
+        if (value < 0 || value >= max_value) {
+          const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
+          value = max_value;
+          int nbyp = 0;
+          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+          if (live) {
+            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+          }
+        }
+        const EncRec rec = s_tab[value];
+        const uint32_t freq = rec.freq ? rec.freq : 65536u;
+        if (x >= ((uint64_t)freq << 47)) {
+          if (live) sink.put((uint32_t)x);
+          x >>= 32;
+        }
+        const uint64_t q = __umul64hi(x, rec.rcp) >> rec.shift;
+        x = x + rec.bias + q * (uint64_t)(65536u - freq);
+      }
+    }
+  }
+  if (live) {
+    sink.put((uint32_t)(x >> 32));
+    sink.put((uint32_t)x);
+    nwords[b] = cap_words - sink.wp;
+    if (sink.overflow) atomicOr(status, 1);
+  }
+}
+
+struct PrefetchSource {
+  const uint32_t *p;
+  int nw, pos;  // pos = index of w0 in the stream
+  uint32_t w0, w1;
+  bool over;
+  __device__ inline void init(const uint32_t *ptr, int n) {
+    p = ptr; nw = n; pos = 0; over = false;
+    w0 = (0 < nw) ? p[0] : 0u;
+    w1 = (1 < nw) ? p[1] : 0u;
+  }
+  __device__ inline uint32_t next() {
+    if (pos >= nw) over = true;
+    const uint32_t r = w0;
+    w0 = w1;
+    w1 = (pos + 2 < nw) ? p[pos + 2] : 0u;
+    ++pos;
+    return r;
+  }
+};
+
+__device__ inline uint32_t get_bits4p(uint64_t &x, PrefetchSource &src) {
+  const uint32_t val = (uint32_t)(x & 15u);
+  x >>= 4;
+  if (x < RANS_L) x = (x << 32) | src.next();
+  return val;
+}
+
+__global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__restrict__ in,
+                                                               const int64_t *__restrict__ byte_off, long ssb, long ssi,
+                                                               int C, int plane, const int32_t *__restrict__ cdf,
+                                                               int cdf_stride, const int32_t *__restrict__ cdf_len,
+                                                               const int32_t *__restrict__ offset,
+                                                               int32_t *__restrict__ symbols, int32_t *__restrict__ status,
+                                                               int B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(smem_raw);                   // [cdf_stride]
+  uint8_t *s_lut = reinterpret_cast<uint8_t *>(smem_raw) + (size_t)cdf_stride * 4;  // [256] when rows <= 256 entries
+  uint16_t *s_lut16 = reinterpret_cast<uint16_t *>(s_lut);
+  const bool wide = cdf_stride > 256;
+  const int lane = threadIdx.x;
+  const int b_raw = blockIdx.x * 64 + lane;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;
+  PrefetchSource src;
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4));
+  uint64_t x = (uint64_t)src.next();
+  x |= (uint64_t)src.next() << 32;
+  int32_t *sp = symbols + (size_t)b * ssb;
+  for (int c = 0; c < C; ++c) {
+    const int len = cdf_len[c];
+    const int32_t max_value = len - 2;
+    const int32_t off = offset[c];
+    __syncthreads();
+    for (int e = lane; e < len; e += 64) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
+    __syncthreads();
+    // LUT over the top 8 bits of cf: largest s with cdf[s] <= k << 8
+    for (int k = lane; k < 256; k += 64) {
+      const uint32_t key = (uint32_t)k << 8;
+      int lo = 0, hi = len - 1;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_cdf[mid] <= key) lo = mid; else hi = mid;
+      }
+      if (wide) s_lut16[k] = (uint16_t)lo; else s_lut[k] = (uint8_t)lo;
+    }
+    __syncthreads();
+    for (int p = 0; p < plane; ++p) {
+      const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+      int s = wide ? (int)s_lut16[cf >> 8] : (int)s_lut[cf >> 8];
+      uint32_t lo = s_cdf[s], hi = s_cdf[s + 1];
+      while (hi <= cf) { lo = hi; ++s; hi = s_cdf[s + 1]; }
+      x = (uint64_t)(hi - lo) * (x >> 16) + cf - lo;
+      if (x < RANS_L) x = (x << 32) | src.next();
+      int32_t value = s;
+      if (value == max_value) {
+        uint32_t val = get_bits4p(x, src);
+        int nb = (int)val;
+        while (val == 15u && nb < 64) { val = get_bits4p(x, src); nb += (int)val; }
+        uint32_t raw = 0;
+        for (int j = 0; j < nb; ++j) {
+          const uint32_t nib = get_bits4p(x, src);
+          if (j < 8) raw |= nib << (j * 4);
+        }
+        value = (int32_t)(raw >> 1);
+        value = (raw & 1u) ? -value - 1 : value + max_value;
+      }
+      if (live) sp[(size_t)((size_t)c * plane + p) * ssi] = value + off;
+    }
+  }
+  if (live && src.over) atomicOr(status, 1);
+}
+
 }  // namespace licos
 
 using namespace licos;
@@ -160,9 +324,15 @@ int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long
   LICOS_REQUIRE(symbols && cdf_len && offset && enc_table && words && nwords && status, "rans_encode_batch: NULL buffer");
   LICOS_REQUIRE(B > 0 && n > 0 && cap_words >= 2 && cdf_stride > 1, "rans_encode_batch: bad sizes B=%d n=%d cap=%d", B, n, cap_words);
   LICOS_REQUIRE(indexes || plane > 0, "rans_encode_batch: need indexes or a plane size");
-  hipLaunchKernelGGL(rans_encode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), symbols, indexes, ssb, ssi,
-                     n, plane, cdf_stride, cdf_len, offset, static_cast<const EncRec *>(enc_table), words, cap_words,
-                     nwords, status, B);
+  if (!indexes && n % plane == 0 && (size_t)cdf_stride * sizeof(EncRec) <= 64 * 1024) {
+    hipLaunchKernelGGL(rans_encode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * sizeof(EncRec),
+                       as_stream(stream), symbols, ssb, ssi, n / plane, plane, cdf_stride, cdf_len, offset,
+                       static_cast<const EncRec *>(enc_table), words, cap_words, nwords, status, B);
+  } else {
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), symbols, indexes, ssb,
+                       ssi, n, plane, cdf_stride, cdf_len, offset, static_cast<const EncRec *>(enc_table), words,
+                       cap_words, nwords, status, B);
+  }
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
@@ -184,8 +354,14 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  hipLaunchKernelGGL(rans_decode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), in, byte_off, indexes, ssb,
-                     ssi, n, plane, cdf, cdf_stride, cdf_len, offset, symbols, status, B);
+  if (!indexes && n % plane == 0 && (size_t)cdf_stride * 4 + 512 <= 64 * 1024) {
+    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * 4 + 512,
+                       as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
+                       symbols, status, B);
+  } else {
+    hipLaunchKernelGGL(rans_decode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), in, byte_off, indexes,
+                       ssb, ssi, n, plane, cdf, cdf_stride, cdf_len, offset, symbols, status, B);
+  }
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

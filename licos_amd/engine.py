@@ -17,6 +17,22 @@ from .layers import GDN, conv_geometry
 
 _cache = weakref.WeakKeyDictionary()
 
+# Optional per-stage device timing (bench.py): when set to a dict, every stage launch is bracketed by
+# HIP events recorded on the stream the kernel is launched on; key = (kind, Cin, Cout, H, W).
+stage_events = None
+
+
+def _timed(key, fn):
+    if stage_events is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    stage_events.setdefault(key, []).append((e0, e1))
+    return out
+
 
 def _pver(p):
     return None if p is None else (p.data_ptr(), p._version, str(p.device))
@@ -88,9 +104,12 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False):
         gp = _packed_gdn(g) if g is not None else None
         if isinstance(m, nn.ConvTranspose2d):
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
-            cur = ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, out_nchw=last,
-                                      clamp01=clamp01 and last)
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
+            cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
+                                                          out_nchw=last, clamp01=clamp01 and last))
         else:
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
-            cur = ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, out_nchw=last)
+            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
+            cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
+                                                        out_nchw=last))
     return cur

@@ -75,6 +75,9 @@ class CompressionModel(nn.Module):
         if precision not in ("fp32", "fp16"):
             raise ValueError("precision must be 'fp32' or 'fp16'")
         self.precision = precision
+        for m in self.children():
+            if isinstance(m, TransformSequential):
+                m.precision = precision
         return self
 
 

@@ -291,3 +291,23 @@ def test_ragged_and_empty_inputs():
         net.decompress([[b"\x00" * 6]], (5, 7))  # not a whole number of words
     with pytest.raises(ValueError):
         net.decompress([[b"\x00" * 8]], (5, 7))  # stream ends early
+
+
+@pytest.mark.parametrize("batch", [1, 3, 64, 130])
+def test_rans_plane_path_with_escapes(batch):
+    """The lock-step LDS-staged coder (the EntropyBottleneck case) on latents that leave the tables
+    on both sides, incl. far outliers (multi-nibble bypass), for ragged wave fill (batch % 64 != 0)."""
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=21)
+    net = _load(3, sd)
+    eb = net.entropy_bottleneck
+    om.eb_update(sd)
+    g = torch.Generator().manual_seed(batch)
+    y = 9 * torch.randn(batch, 192, 4, 6, generator=g)
+    y[0, 5, 1, 2] = 1234.5
+    y[-1, 100, 0, 0] = -70000.25
+    y[batch // 2, 191, 3, 5] = 3.0e6
+    strings = eb.compress(y.to(DEV))
+    ref = om.eb_compress(y, sd)
+    assert strings == ref
+    out = eb.decompress(strings, (4, 6))
+    assert torch.equal(out.cpu(), om.eb_decompress(ref, (4, 6), sd))

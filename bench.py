@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
+    ap.add_argument("--chunk", type=int, default=1024, help="tiles per pipeline chunk inside a step")
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--quality", type=int, default=3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
@@ -77,6 +78,7 @@ def main():
     torch.manual_seed(42)
     net = licos_amd.get_model("bmshj2018-factorized", False, args.channels, args.quality)
     net = net.to(dev).eval().set_precision(args.precision)
+    net.chunk = args.chunk
     with torch.no_grad():
         synthetic.make_trained_like(net, seed=0)
     B = args.batch

@@ -87,8 +87,9 @@ def stages(seq):
     return out
 
 
-def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False):
-    """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32."""
+def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
+    """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32
+    (written into `out` when given)."""
     st = stages(seq)
     if x_blk is None:
         if x.dtype != torch.float32:
@@ -106,10 +107,11 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False):
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
             cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
-                                                          out_nchw=last, clamp01=clamp01 and last))
+                                                          out_nchw=last, clamp01=clamp01 and last,
+                                                          out=out if last else None))
         else:
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
-                                                        out_nchw=last))
+                                                        out_nchw=last, out=out if last else None))
     return cur

@@ -91,6 +91,7 @@ class FactorizedPrior(CompressionModel):
         self.N = N
         self.M = M
         self.precision = precision
+        self.chunk = 1024  # tiles per pipeline chunk of the fp16 codec (licos_amd/codec.py)
 
     @property
     def downsampling_factor(self):
@@ -109,6 +110,9 @@ class FactorizedPrior(CompressionModel):
 
     def compress(self, x):
         self._sync_precision()
+        if self.precision == "fp16":
+            from .codec import compress_fp16
+            return compress_fp16(self, x, chunk=self.chunk)
         y = self.g_a(x)
         y_strings = self.entropy_bottleneck.compress(y)
         return {"strings": [y_strings], "shape": y.size()[-2:]}
@@ -116,6 +120,9 @@ class FactorizedPrior(CompressionModel):
     def decompress(self, strings, shape):
         assert isinstance(strings, list) and len(strings) == 1
         self._sync_precision()
+        if self.precision == "fp16":
+            from .codec import decompress_fp16
+            return decompress_fp16(self, strings, shape, chunk=self.chunk)
         y_hat = self.entropy_bottleneck.decompress(strings[0], shape)
         x_hat = self.g_s(y_hat).clamp_(0, 1)
         return {"x_hat": x_hat}

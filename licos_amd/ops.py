@@ -148,14 +148,21 @@ def eb_pack(matrices, biases, factors, filters, channels):
     return packed
 
 
-def eb_quantize(y, medians, mode, noise=None, symbols=None, sym_stride_b=0, sym_stride_i=1, want_y_hat=True):
-    """mode: 'dequantize' | 'noise' | 'symbols'.  y: (B, C, *spatial) fp32."""
+def _p_off(t, elem_off):
+    return ctypes.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+
+def eb_quantize(y, medians, mode, noise=None, symbols=None, sym_stride_b=0, sym_stride_i=1, want_y_hat=True,
+                sym_offset=0):
+    """mode: 'dequantize' | 'noise' | 'symbols'.  y: (B, C, *spatial) fp32.  `sym_offset`: element offset of
+    this batch's first stream inside a larger interleaved symbol buffer."""
     _dev(y, medians, noise, symbols)
     b, c = y.shape[:2]
     hw = y[0, 0].numel()
     m = {"dequantize": 0, "noise": 1, "symbols": 2}[mode]
     y_hat = torch.empty_like(y) if (want_y_hat and m != 2) else None
-    rc = _lib.load().licos_eb_quantize(_p(_f32(y)), _p(_f32(medians)), _p(noise), _p(y_hat), _p(symbols),
+    sp = _p(symbols) if symbols is None else _p_off(symbols, sym_offset)
+    rc = _lib.load().licos_eb_quantize(_p(_f32(y)), _p(_f32(medians)), _p(noise), _p(y_hat), sp,
                                        sym_stride_b, sym_stride_i, m, b, c, hw, _stream())
     _lib.check(rc, "eb_quantize")
     return y_hat
@@ -173,10 +180,10 @@ def eb_likelihood(v, packed, filters, bound, form=0, sum_log2=None):
     return lik
 
 
-def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want_nchw=True, blk16=None):
+def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want_nchw=True, blk16=None, sym_offset=0):
     _dev(symbols, medians, blk16)
     y = torch.empty((b, c, h, w), device=symbols.device, dtype=torch.float32) if want_nchw else None
-    rc = _lib.load().licos_eb_dequantize(_p(symbols), sym_stride_b, sym_stride_i, _p(medians), _p(y), _p(blk16),
+    rc = _lib.load().licos_eb_dequantize(_p_off(symbols, sym_offset), sym_stride_b, sym_stride_i, _p(medians), _p(y), _p(blk16),
                                          b, c, h, w, _stream())
     _lib.check(rc, "eb_dequantize")
     return y
@@ -192,35 +199,40 @@ def reduce_sqdiff(a, b, clamp01=False):
 
 # ----------------------------------------------------------------------------- rANS
 def rans_encode_batch(symbols, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, enc_table, cap_words,
-                      batch, indexes=None):
+                      batch, indexes=None, sym_offset=0):
     """Returns (words scratch [cap_words, B] u32, nwords [B] i32, status [1] i32) on the device."""
     _dev(symbols, cdf, cdf_len, offset, enc_table, indexes)
     dev = symbols.device
     words = torch.empty((cap_words, batch), device=dev, dtype=torch.int32)
     nwords = torch.empty(batch, device=dev, dtype=torch.int32)
     status = torch.zeros(1, device=dev, dtype=torch.int32)
-    rc = _lib.load().licos_rans_encode_batch(_p(symbols), _p(indexes), sym_stride_b, sym_stride_i, n, plane, _p(cdf),
+    ip = _p(indexes) if indexes is None else _p_off(indexes, sym_offset)
+    rc = _lib.load().licos_rans_encode_batch(_p_off(symbols, sym_offset), ip, sym_stride_b, sym_stride_i, n, plane, _p(cdf),
                                              cdf.shape[1], _p(cdf_len), _p(offset), _p(enc_table), _p(words),
                                              cap_words, _p(nwords), _p(status), batch, _stream())
     _lib.check(rc, "rans_encode_batch")
     return words, nwords, status
 
 
-def rans_compact(words, nwords, byte_off, total_bytes):
-    _dev(words, nwords, byte_off)
+def rans_compact(words, nwords, byte_off, total_bytes, out=None, off_offset=0):
+    """`byte_off` holds absolute byte offsets into `out`; `off_offset` selects this batch's first entry."""
+    _dev(words, nwords, byte_off, out)
     cap, batch = words.shape
-    out = torch.empty(max(int(total_bytes), 4), device=words.device, dtype=torch.uint8)
-    rc = _lib.load().licos_rans_compact(_p(words), cap, _p(nwords), _p(byte_off), _p(out), batch, _stream())
+    if out is None:
+        out = torch.empty(max(int(total_bytes), 4), device=words.device, dtype=torch.uint8)
+    rc = _lib.load().licos_rans_compact(_p(words), cap, _p(nwords), _p_off(byte_off, off_offset), _p(out), batch, _stream())
     _lib.check(rc, "rans_compact")
     return out
 
 
 def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, symbols, batch,
-                      indexes=None):
+                      indexes=None, sym_offset=0, status=None):
     _dev(data, byte_off, cdf, cdf_len, offset, symbols, indexes)
-    status = torch.zeros(1, device=data.device, dtype=torch.int32)
-    rc = _lib.load().licos_rans_decode_batch(_p(data), _p(byte_off), _p(indexes), sym_stride_b, sym_stride_i, n, plane,
-                                             _p(cdf), cdf.shape[1], _p(cdf_len), _p(offset), _p(symbols), _p(status),
+    if status is None:
+        status = torch.zeros(1, device=data.device, dtype=torch.int32)
+    ip = _p(indexes) if indexes is None else _p_off(indexes, sym_offset)
+    rc = _lib.load().licos_rans_decode_batch(_p(data), _p_off(byte_off, sym_offset), ip, sym_stride_b, sym_stride_i, n, plane,
+                                             _p(cdf), cdf.shape[1], _p(cdf_len), _p(offset), _p_off(symbols, sym_offset), _p(status),
                                              batch, _stream())
     _lib.check(rc, "rans_decode_batch")
     return status
@@ -296,14 +308,22 @@ def blk16_to_nchw_f32(x, c):
     return y
 
 
-def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False):
-    _dev(x_blk, w_packed, bias_padded, gdn_packed)
+def _out_nchw(out, shape, device):
+    if out is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32:
+        raise ValueError(f"licos_amd: output tensor must be float32 of shape {shape}")
+    return out
+
+
+def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, out=None):
+    _dev(x_blk, w_packed, bias_padded, gdn_packed, out)
     b, c16, h, w, _ = x_blk.shape
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("conv5x5s2_f16: input is not the blk16 fp16 layout of `cin` channels")
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     if out_nchw:
-        y = torch.empty((b, cout, ho, wo), device=x_blk.device, dtype=torch.float32)
+        y = _out_nchw(out, (b, cout, ho, wo), x_blk.device)
         yb, yn = None, y
     else:
         y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)
@@ -314,14 +334,15 @@ def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
     return y
 
 
-def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, clamp01=False):
-    _dev(x_blk, w_packed, bias_padded, gdn_packed)
+def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, clamp01=False,
+                    out=None):
+    _dev(x_blk, w_packed, bias_padded, gdn_packed, out)
     b, c16, h, w, _ = x_blk.shape
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("deconv5x5s2_f16: input is not the blk16 fp16 layout of `cin` channels")
     ho, wo = 2 * h, 2 * w
     if out_nchw:
-        y = torch.empty((b, cout, ho, wo), device=x_blk.device, dtype=torch.float32)
+        y = _out_nchw(out, (b, cout, ho, wo), x_blk.device)
         yb, yn = None, y
     else:
         y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)

@@ -39,6 +39,27 @@ struct ConvGeom {  // stride-2 5x5 conv: output tile TH x TW, input patch (2TH+3
   static constexpr int HALF = PH * 2 * PWH;        // granules per 8-channel half
   static constexpr int PATCH_BYTES = 2 * HALF * 16;
 };
+// Double-buffered stride-2 conv (mfma_conv.hip): per K-step (cin chunk, kernel row ky) only the TH input
+// rows 2*ty + ky that step reads are staged, as granules [half][ty][x-parity][x/2].
+template <int MT, int TH, int TW>
+struct ConvStepGeom {
+  static constexpr int PWH = (TW == 16) ? 24 : round_up(TW + 2, 4);  // 2*PWH % 16 == 0 keeps 2-row tiles conflict-free
+  static constexpr int ROWG = 2 * PWH;            // granules per (half, ty): both parities
+  static constexpr int HALF = TH * ROWG;
+  static constexpr int PATCH_GRAN = 2 * HALF;     // multiple of 64 for every instantiated tile
+  static constexpr int W_GRAN = 5 * MT * 64;      // one kernel row of A fragments
+  static constexpr int BUF_GRAN = PATCH_GRAN + W_GRAN;
+  static constexpr int GAMMA_GRAN = MT * MT * 2 * 64;
+  static constexpr int LDS_BYTES = 16 * ((2 * BUF_GRAN > GAMMA_GRAN) ? 2 * BUF_GRAN : GAMMA_GRAN);
+  static_assert(PATCH_GRAN % 64 == 0, "patch must be a whole number of wave-wide LDS-DMA pieces");
+};
+
+// 16 B global -> LDS without a register round trip: LDS address = wave-uniform base + lane * 16.
+__device__ inline void glds16(const void *gsrc, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
 template <int TH, int TW>
 struct DeconvGeom {  // one output phase of a stride-2 5x5 transposed conv: input tile TH x TW, patch (TH+2) x (TW+2)
   static constexpr int PH = TH + 2;
@@ -60,12 +81,13 @@ struct MfmaArgs {
   int Ho, Wo, Cout;       // output geometry; Cout = real channel count (<= 32*MT)
   int tiles_x, tiles_y;
   int clamp01;
+  const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
 };
 
 // ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
 template <int MT, int NT, int EPI>
-__device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, int b, const int (&oy)[NT],
-                                      const int (&ox)[NT], int lane) {
+__device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, const bf16x8 *gamma, int b,
+                                      const int (&oy)[NT], const int (&ox)[NT], int lane) {
   const int h = lane >> 5;
   // bias: channel of register q in tile mt is 32mt + (q&3) + 8(q>>2) + 4h
 #pragma unroll
@@ -104,7 +126,7 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
       for (int jt = 0; jt < MT; ++jt) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const bf16x8 gfrag = a.gamma[((it * MT + jt) * 2 + s) * 64 + lane];
+          const bf16x8 gfrag = gamma[((it * MT + jt) * 2 + s) * 64 + lane];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             bf16x8 sq;

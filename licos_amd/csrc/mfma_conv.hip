@@ -1,16 +1,20 @@
-// MFMA conv kernels (see mfma_common.hpp for the design notes).
+// MFMA stride-2 5x5 convolution (see mfma_common.hpp for the design notes).
+//
+// K loop = (cin chunk of 16) x (kernel row ky): 5*Cin/16 steps.  Each step needs the TH input rows
+// 2*ty + ky of the chunk (both x parities) and one kernel row of weight fragments (5 taps x MT KB).
+// Both are brought in by LDS-DMA (global_load_lds_dwordx4, no VGPRs) into the buffer the NEXT step
+// will read while the MFMAs of the current step run on the other buffer: one s_barrier per step,
+// 2 workgroups per CU (77 KB of LDS each at MT=4).
 #include "mfma_common.hpp"
 
 namespace licos {
 
-// ---- stride-2 5x5 convolution --------------------------------------------------------------------
 template <int MT, int NT, int TH, int TW, int EPI>
 __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
-  using G = ConvGeom<TH, TW>;
+  using G = ConvStepGeom<MT, TH, TW>;
   static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  half8 *s_patch = reinterpret_cast<half8 *>(smem);
-  half8 *s_w = reinterpret_cast<half8 *>(smem + G::PATCH_BYTES);  // [5 taps][MT][64 lanes]
+  half8 *s_buf = reinterpret_cast<half8 *>(smem);  // [2][BUF_GRAN]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
     const int ty = p / TW, tx = p % TW;
     oy[nt] = oy0 + ty;
     ox[nt] = ox0 + tx;
-    base[nt] = h * G::HALF + (2 * ty) * (2 * G::PWH) + tx;
+    base[nt] = h * G::HALF + ty * G::ROWG + tx;
   }
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -36,48 +40,78 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
       for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
 
   const size_t plane = (size_t)a.H * a.W;
-  for (int cc = 0; cc < a.Cin16; ++cc) {
-    const half8 *xin = reinterpret_cast<const half8 *>(a.x) + ((size_t)b * a.Cin16 + cc) * plane * 2;
-    for (int ky = 0; ky < 5; ++ky) {
-      __syncthreads();  // everyone is done reading the previous slab (and patch, when cc changes)
-      if (ky == 0) {
-        // patch: global order (row, x, half) is contiguous per row; scatter to [half][row][parity][x/2]
-        for (int g = tid; g < G::PH * G::PW * 2; g += 256) {
-          const int hh = g & 1, q = (g >> 1) % G::PW, row = (g >> 1) / G::PW;
-          const int iy = iy0 + row, ix = ix0 + q;
-          half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = xin[((size_t)iy * a.W + ix) * 2 + hh];
-          s_patch[hh * G::HALF + (row * 2 + (q & 1)) * G::PWH + (q >> 1)] = v;
-        }
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
+
+  // issue the LDS-DMA pieces of K-step `step` into buffer `buf` (each wave every 4th piece)
+  auto stage = [&](int step, int buf) {
+    const int cc = step / 5, ky = step - 5 * cc;
+    const half8 *xin = xb + (size_t)cc * plane * 2;
+    const half8 *wsrc = a.wp + (size_t)step * G::W_GRAN;
+    half8 *dst = s_buf + buf * G::BUF_GRAN;
+    constexpr int PQ = G::PATCH_GRAN / 64, Q = G::BUF_GRAN / 64;
+    for (int q = wave; q < Q; q += 4) {
+      const half8 *src;
+      if (q < PQ) {
+        const int d = q * 64 + lane;
+        const int hh = d / G::HALF, rem = d - hh * G::HALF;
+        const int j = rem / G::ROWG, r2 = rem - j * G::ROWG;
+        const int par = r2 / G::PWH, xh = r2 - par * G::PWH;
+        const int iy = iy0 + 2 * j + ky, ix = ix0 + 2 * xh + par;
+        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        src = ok ? xin + ((size_t)iy * a.W + ix) * 2 + hh : zero;
+      } else {
+        src = wsrc + (q - PQ) * 64 + lane;
       }
-      const half8 *wsrc = a.wp + ((size_t)(cc * 5 + ky) * 5 * MT) * 64;
-      for (int g = tid; g < 5 * MT * 64; g += 256) s_w[g] = wsrc[g];
-      __syncthreads();
+      glds16(src, dst + q * 64);
+    }
+  };
+
+  const int S = a.Cin16 * 5;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < S) stage(s + 1, cur ^ 1);
+    const half8 *s_patch = s_buf + cur * G::BUF_GRAN;
+    const half8 *s_w = s_patch + G::PATCH_GRAN;
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        half8 bf[NT];
+    for (int kx = 0; kx < 5; ++kx) {
+      half8 bf[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + ky * (2 * G::PWH) + (kx & 1) * G::PWH + (kx >> 1)];
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + (kx & 1) * G::PWH + (kx >> 1)];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const half8 af = s_w[(kx * MT + mt) * 64 + lane];
+      for (int mt = 0; mt < MT; ++mt) {
+        const half8 af = s_w[(kx * MT + mt) * 64 + lane];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
       }
     }
+    // my DMA pieces for the next step have landed; after the barrier so have everyone's, and every
+    // wave is done reading `cur`, which the step after next overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  epilogue_store<MT, NT, EPI>(acc, a, b, oy, ox, lane);
+  const bf16x8 *gam = a.gamma;
+  if (EPI != EPI_NONE) {
+    // gamma fragments are read by all 4 waves: stage them once in the (now free) LDS
+    bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
+    for (int g = tid; g < G::GAMMA_GRAN; g += 256) s_gamma[g] = a.gamma[g];
+    __syncthreads();
+    gam = s_gamma;
+  }
+  epilogue_store<MT, NT, EPI>(acc, a, gam, b, oy, ox, lane);
 }
 
 template <int MT, int NT, int TH, int TW, int EPI>
 static int launch_conv(const MfmaArgs &a0, hipStream_t s) {
-  using G = ConvGeom<TH, TW>;
+  using G = ConvStepGeom<MT, TH, TW>;
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.Wo, TW);
   a.tiles_y = cdiv(a.Ho, TH);
-  const size_t lds = G::PATCH_BYTES + (size_t)5 * MT * 1024;
+  const size_t lds = G::LDS_BYTES;
   auto kern = conv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -90,16 +124,16 @@ static int launch_conv(const MfmaArgs &a0, hipStream_t s) {
   return LICOS_OK;
 }
 
-
 template <int MT, int EPI>
 static int dispatch_tile(const MfmaArgs &a, int width, hipStream_t s) {
-  if (MT <= 4) {
+  if constexpr (MT <= 4) {
     if (width >= 32) return launch_conv<MT, 2, 8, 32, EPI>(a, s);
     return launch_conv<MT, 2, 16, 16, EPI>(a, s);
+  } else {
+    // wide channel counts: one pixel tile per wave keeps the accumulators within the register file
+    if (width >= 32) return launch_conv<MT, 1, 4, 32, EPI>(a, s);
+    return launch_conv<MT, 1, 8, 16, EPI>(a, s);
   }
-  // wide channel counts: one pixel tile per wave keeps the accumulators within the register file
-  if (width >= 32) return launch_conv<MT, 1, 4, 32, EPI>(a, s);
-  return launch_conv<MT, 1, 8, 16, EPI>(a, s);
 }
 
 int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s) {

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
       }
     }
   }
-  epilogue_store<MT, NT, EPI>(acc, a, b, oy, ox, lane);
+  epilogue_store<MT, NT, EPI>(acc, a, a.gamma, b, oy, ox, lane);
 }
 
 template <int MT, int NT, int TH, int TW, int EPI>

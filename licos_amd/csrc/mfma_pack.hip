@@ -1,4 +1,6 @@
 // MFMA path: operand packing, layout conversion and the C entry points.
+#include <cstdlib>
+
 #include "mfma_common.hpp"
 
 namespace licos {
@@ -176,6 +178,17 @@ int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, 
   return LICOS_OK;
 }
 
+// 16 zero bytes in device memory: the LDS-DMA source for halo granules that fall outside the image.
+static const void *zero_page() {
+  static void *p = [] {
+    void *q = nullptr;
+    if (hipMalloc(&q, 256) != hipSuccess) return (void *)nullptr;
+    if (hipMemset(q, 0, 256) != hipSuccess) return (void *)nullptr;
+    return q;
+  }();
+  return p;
+}
+
 static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bias, const void *gdn, int epi,
                      void *y_blk, float *y_nchw, int B, int Cin, int H, int W, int Cout, int *MT_out, const char *who) {
   LICOS_REQUIRE(x && wp && bias, "%s: NULL buffer", who);
@@ -199,6 +212,8 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   a.W = W;
   a.Cout = Cout;
   a.clamp01 = 0;
+  a.zero16 = zero_page();
+  LICOS_REQUIRE(a.zero16 != nullptr, "%s: could not allocate the zero page", who);
   *MT_out = MT;
   return LICOS_OK;
 }

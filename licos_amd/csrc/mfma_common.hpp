@@ -163,7 +163,7 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
           if (c0 < Cout16 * 16) {
             half4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (c0 + e < a.Cout) ? (_Float16)v[e] : (_Float16)0.f;
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];  // padded channels carry zero weights and bias
             _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + (c0 >> 4)) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + (c0 & 15);
             *reinterpret_cast<half4 *>(dst) = o;
           }

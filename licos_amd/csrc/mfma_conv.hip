@@ -43,27 +43,40 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
   const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
-  // issue the LDS-DMA pieces of K-step `step` into buffer `buf` (each wave every 4th piece)
+  // LDS-DMA pieces (64 granules each) are dealt round-robin to the 4 waves.  Everything about a patch
+  // piece except the kernel row is fixed for the whole K loop, so it is computed once here: the
+  // granule's offset from the chunk's (iy0, ix0) pixel, its first input row and whether its column
+  // lies inside the image.
+  constexpr int PQ = G::PATCH_GRAN / 64, WQ = G::W_GRAN / 64;
+  constexpr int NPP = (PQ + 3) / 4, NWP = (WQ + 3) / 4;
+  int p_off[NPP], p_row[NPP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int d = (wave + 4 * i) * 64 + lane;
+    const int hh = d / G::HALF, rem = d - hh * G::HALF;
+    const int j = rem / G::ROWG, r2 = rem - j * G::ROWG;
+    const int par = r2 / G::PWH, xh = r2 - par * G::PWH;
+    const int ix = ix0 + 2 * xh + par;
+    p_off[i] = ((2 * j) * a.W + ix) * 2 + hh;                 // half8 units from row iy0 of the chunk plane
+    p_row[i] = (ix >= 0 && ix < a.W) ? iy0 + 2 * j : -(1 << 20);  // out-of-image columns never validate
+  }
   auto stage = [&](int step, int buf) {
     const int cc = step / 5, ky = step - 5 * cc;
-    const half8 *xin = xb + (size_t)cc * plane * 2;
-    const half8 *wsrc = a.wp + (size_t)step * G::W_GRAN;
+    const half8 *xrow = xb + (size_t)cc * plane * 2 + (ptrdiff_t)(iy0 + ky) * a.W * 2;
+    const half8 *wsrc = a.wp + (size_t)step * G::W_GRAN + lane;
     half8 *dst = s_buf + buf * G::BUF_GRAN;
-    constexpr int PQ = G::PATCH_GRAN / 64, Q = G::BUF_GRAN / 64;
-    for (int q = wave; q < Q; q += 4) {
-      const half8 *src;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int q = wave + 4 * i;
       if (q < PQ) {
-        const int d = q * 64 + lane;
-        const int hh = d / G::HALF, rem = d - hh * G::HALF;
-        const int j = rem / G::ROWG, r2 = rem - j * G::ROWG;
-        const int par = r2 / G::PWH, xh = r2 - par * G::PWH;
-        const int iy = iy0 + 2 * j + ky, ix = ix0 + 2 * xh + par;
-        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        src = ok ? xin + ((size_t)iy * a.W + ix) * 2 + hh : zero;
-      } else {
-        src = wsrc + (q - PQ) * 64 + lane;
+        const bool ok = (unsigned)(p_row[i] + ky) < (unsigned)a.H;
+        glds16(ok ? xrow + p_off[i] : zero, dst + q * 64);
       }
-      glds16(src, dst + q * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int q = wave + 4 * i;
+      if (q < WQ) glds16(wsrc + q * 64, dst + G::PATCH_GRAN + q * 64);
     }
   };
 

@@ -1,17 +1,21 @@
-// MFMA deconv kernels (see mfma_common.hpp for the design notes).
+// MFMA stride-2 5x5 transposed convolution (see mfma_common.hpp for the design notes).
+//
+// out[2ty+py][2tx+px] = sum over ky = py (mod 2), kx = px (mod 2) of
+//                       in[ty + (py+2-ky)/2][tx + (px+2-kx)/2] * w[ky][kx]
+// so each of the 4 output phases is a stride-1 convolution with 3x3 / 3x2 / 2x3 / 2x2 taps.  A
+// workgroup computes one phase of a TH x TW input tile (all output channels); its K loop walks
+// (cin chunk) x (kernel row of the phase), each step LDS-DMA'd into the buffer the next step reads
+// while the MFMAs of the current one run (same scheme as mfma_conv.hip; 3 workgroups per CU).
 #include "mfma_common.hpp"
 
 namespace licos {
 
-// ---- stride-2 5x5 transposed convolution, one output phase per workgroup ---------------------------
-// out[2ty+py][2tx+px] = sum over ky = py (mod 2), kx = px (mod 2) of in[ty + (py+2-ky)/2][tx + (px+2-kx)/2] w[ky][kx]
 template <int MT, int NT, int TH, int TW, int EPI>
 __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
-  using G = DeconvGeom<TH, TW>;
+  using G = DeconvStepGeom<MT, TH, TW>;
   static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  half8 *s_patch = reinterpret_cast<half8 *>(smem);
-  half8 *s_w = reinterpret_cast<half8 *>(smem + G::PATCH_BYTES);  // [<=9 taps][MT][64]
+  half8 *s_buf = reinterpret_cast<half8 *>(smem);  // [2][BUF_GRAN]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
     const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W;
     oy[nt] = in ? 2 * (ty0 + ty) + py : -1;
     ox[nt] = 2 * (tx0 + tx) + px;
-    base[nt] = h * G::HALF + (ty + 1) * G::RS + (tx + 1);
+    base[nt] = h * G::HALF + ty * G::RS + (tx + 1);
   }
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -41,47 +45,87 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
       for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
 
   const size_t plane = (size_t)a.H * a.W;
-  for (int cc = 0; cc < a.Cin16; ++cc) {
-    const half8 *xin = reinterpret_cast<const half8 *>(a.x) + ((size_t)b * a.Cin16 + cc) * plane * 2;
-    __syncthreads();
-    for (int g = tid; g < G::PH * G::PW * 2; g += 256) {
-      const int hh = g & 1, q = (g >> 1) % G::PW, row = (g >> 1) / G::PW;
-      const int iy = ty0 - 1 + row, ix = tx0 - 1 + q;
-      half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = xin[((size_t)iy * a.W + ix) * 2 + hh];
-      s_patch[hh * G::HALF + row * G::RS + q] = v;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
+
+  // per-lane description of this wave's patch pieces (fixed for the whole K loop)
+  constexpr int PQ = G::PATCH_GRAN / 64, NPP = (PQ + 3) / 4, NWP = (3 * MT + 3) / 4;
+  int p_off[NPP], p_row[NPP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int d = (wave + 4 * i) * 64 + lane;
+    const int hh = d / G::HALF, rem = d - hh * G::HALF;
+    const int j = rem / G::RS, q = rem - j * G::RS;
+    const int ix = tx0 - 1 + q;
+    p_off[i] = (j * a.W + ix) * 2 + hh;
+    p_row[i] = (ix >= 0 && ix < a.W && j < TH && q < TW + 2) ? ty0 + j : -(1 << 20);
+  }
+  const int wq = nkx * MT;  // weight pieces per step
+  auto stage = [&](int step, int buf) {
+    const int cc = step / nky, iky = step - nky * cc;
+    const int dy = 1 - iky;  // ky = py + 2*iky -> dy = (py + 2 - ky) / 2
+    const half8 *xrow = xb + (size_t)cc * plane * 2 + (ptrdiff_t)dy * a.W * 2;
+    const half8 *wsrc = a.wp + ((size_t)phase_tap0 * a.Cin16 + (size_t)cc * ntap + (size_t)iky * nkx) * MT * 64 + lane;
+    half8 *dst = s_buf + buf * G::BUF_GRAN;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int q = wave + 4 * i;
+      if (q < PQ) {
+        const bool ok = (unsigned)(p_row[i] + dy) < (unsigned)a.H;
+        glds16(ok ? xrow + (ptrdiff_t)ty0 * a.W * 2 + p_off[i] : zero, dst + q * 64);
+      }
     }
-    const half8 *wsrc = a.wp + ((size_t)phase_tap0 * a.Cin16 + (size_t)cc * ntap) * MT * 64;
-    for (int g = tid; g < ntap * MT * 64; g += 256) s_w[g] = wsrc[g];
-    __syncthreads();
-    for (int iky = 0; iky < nky; ++iky) {
-      const int dy = 1 - iky;  // ky = py + 2*iky  ->  dy = (py + 2 - ky) / 2
-      for (int ikx = 0; ikx < nkx; ++ikx) {
-        const int dx = 1 - ikx;
-        const int t = iky * nkx + ikx;
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int q = wave + 4 * i;
+      if (q < wq) glds16(wsrc + q * 64, dst + G::PATCH_GRAN + q * 64);
+    }
+  };
+
+  const int S = a.Cin16 * nky;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < S) stage(s + 1, cur ^ 1);
+    const half8 *s_patch = s_buf + cur * G::BUF_GRAN;
+    const half8 *s_w = s_patch + G::PATCH_GRAN;
+#pragma unroll
+    for (int ikx = 0; ikx < 3; ++ikx) {
+      if (ikx < nkx) {  // wave-uniform: odd-x phases have 2 taps per kernel row
         half8 bf[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + dy * G::RS + dx];
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + (1 - ikx)];  // dx = (px + 2 - kx) / 2 = 1 - ikx
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const half8 af = s_w[(t * MT + mt) * 64 + lane];
+          const half8 af = s_w[(ikx * MT + mt) * 64 + lane];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  epilogue_store<MT, NT, EPI>(acc, a, a.gamma, b, oy, ox, lane);
+  const bf16x8 *gam = a.gamma;
+  if (EPI != EPI_NONE) {
+    bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
+    for (int g = tid; g < G::GAMMA_GRAN; g += 256) s_gamma[g] = a.gamma[g];
+    __syncthreads();
+    gam = s_gamma;
+  }
+  epilogue_store<MT, NT, EPI>(acc, a, gam, b, oy, ox, lane);
 }
 
 template <int MT, int NT, int TH, int TW, int EPI>
 static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
-  using G = DeconvGeom<TH, TW>;
+  using G = DeconvStepGeom<MT, TH, TW>;
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
-  const size_t lds = G::PATCH_BYTES + (size_t)9 * MT * 1024;
+  const size_t lds = G::LDS_BYTES;
   auto kern = deconv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -94,16 +138,15 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
   return LICOS_OK;
 }
 
-
 template <int MT, int EPI>
 static int dispatch_tile(const MfmaArgs &a, int width, hipStream_t s) {
-  if (MT <= 4) {
+  if constexpr (MT <= 4) {
     if (width >= 32) return launch_deconv<MT, 2, 8, 32, EPI>(a, s);
     return launch_deconv<MT, 2, 16, 16, EPI>(a, s);
+  } else {
+    if (width >= 32) return launch_deconv<MT, 1, 4, 32, EPI>(a, s);
+    return launch_deconv<MT, 1, 8, 16, EPI>(a, s);
   }
-  // wide channel counts: one pixel tile per wave keeps the accumulators within the register file
-  if (width >= 32) return launch_deconv<MT, 1, 4, 32, EPI>(a, s);
-  return launch_deconv<MT, 1, 8, 16, EPI>(a, s);
 }
 
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s) {

@@ -75,6 +75,13 @@ struct DeconvStepGeom {
   static_assert(PATCH_GRAN % 64 == 0, "patch must be a whole number of wave-wide LDS-DMA pieces");
 };
 
+template <int TH, int TW>
+struct DeconvGeom {  // full (TH+2) x (TW+2) input patch of a transposed-conv tile
+  static constexpr int PH = TH + 2;
+  static constexpr int PW = TW + 2;
+  static constexpr int RS = (TW == 16) ? 32 : round_up(TW + 2, 4);
+};
+
 struct MfmaArgs {
   const _Float16 *x;      // blk16 input
   const half8 *wp;        // packed weights (A fragments)
@@ -194,5 +201,6 @@ static inline int mt_for(int Cout) {
 // defined in mfma_conv.hip / mfma_deconv.hip
 int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
+int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 
 }  // namespace licos

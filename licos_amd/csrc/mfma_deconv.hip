@@ -161,3 +161,164 @@ int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStrea
 }
 
 }  // namespace licos
+
+// -----------------------------------------------------------------------------------------------------
+// Last synthesis stage (128 -> 1/3/13 channels, NCHW fp32 out, optional clamp): the output is a few
+// channels wide, so one 32-row accumulator tile per phase holds everything and a workgroup can keep
+// all FOUR phases of its 8x32 input tile in registers (4 x NT x 16).  The input patch is then staged
+// once per cin chunk instead of once per phase and kernel row (the stage is input-read bound: 4 MB
+// of activations per tile against 0.8 MB of output), and a lane owns the 2x2 output pixels of its
+// input pixel, so it stores px = 0/1 as one 8-byte pair: fully coalesced rows.
+namespace licos {
+
+template <int NT, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
+  using G = DeconvGeom<TH, TW>;
+  static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
+  constexpr int HALF = round_up(G::PH * G::RS, 32), PATCH_GRAN = 2 * HALF, BUF_GRAN = PATCH_GRAN + 25 * 64;
+  static_assert(PATCH_GRAN % 64 == 0, "patch must be whole LDS-DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_buf = reinterpret_cast<half8 *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int b = blockIdx.y;
+  const int ty0 = (blockIdx.x / a.tiles_x) * TH, tx0 = (blockIdx.x % a.tiles_x) * TW;
+
+  int base[NT], iy[NT], ix[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = (wave * NT + nt) * 32 + r;
+    const int ty = p / TW, tx = p % TW;
+    iy[nt] = ty0 + ty;
+    ix[nt] = tx0 + tx;
+    base[nt] = h * HALF + (ty + 1) * G::RS + (tx + 1);
+  }
+  f32x16 acc[4][NT];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[ph][nt][q] = 0.f;
+
+  const size_t plane = (size_t)a.H * a.W;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
+
+  constexpr int PQ = PATCH_GRAN / 64, NPP = (PQ + 3) / 4, NWP = (25 + 3) / 4;
+  const half8 *p_src[NPP];
+  bool p_ok[NPP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int d = (wave + 4 * i) * 64 + lane;
+    const int hh = d / HALF, rem = d - hh * HALF;
+    const int j = rem / G::RS, q = rem - j * G::RS;
+    const int yy = ty0 - 1 + j, xx = tx0 - 1 + q;
+    p_ok[i] = j < G::PH && q < G::PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    p_src[i] = xb + ((ptrdiff_t)yy * a.W + xx) * 2 + hh;
+  }
+  // weight piece T (one tap, phase-major order) of chunk cc sits at (tap0(phase) * Cin16 + cc * ntap(phase) + t) * 64
+  int w_mul[NWP], w_add[NWP];
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) {
+    const int T = wave + 4 * i;
+    const int ph = T < 9 ? 0 : T < 15 ? 1 : T < 21 ? 2 : 3;
+    const int tap0 = ph == 0 ? 0 : ph == 1 ? 9 : ph == 2 ? 15 : 21;
+    const int ntap = ph == 0 ? 9 : ph == 3 ? 4 : 6;
+    w_mul[i] = ntap * 64;
+    w_add[i] = (tap0 * a.Cin16 + (T - tap0)) * 64 + lane;
+  }
+  auto stage = [&](int cc, int buf) {
+    half8 *dst = s_buf + buf * BUF_GRAN;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int q = wave + 4 * i;
+      if (q < PQ) glds16(p_ok[i] ? p_src[i] + (size_t)cc * plane * 2 : zero, dst + q * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int T = wave + 4 * i;
+      if (T < 25) glds16(a.wp + (size_t)cc * w_mul[i] + w_add[i], dst + PATCH_GRAN + T * 64);
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int cc = 0; cc < a.Cin16; ++cc) {
+    const int cur = cc & 1;
+    if (cc + 1 < a.Cin16) stage(cc + 1, cur ^ 1);
+    const half8 *s_patch = s_buf + cur * BUF_GRAN;
+    const half8 *s_w = s_patch + PATCH_GRAN;
+    // the 9 distinct shifted views of the patch, shared by the phases that use them
+    half8 bf[3][3][NT];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[dy + 1][dx + 1][nt] = s_patch[base[nt] + dy * G::RS + dx];
+    int T = 0;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+      for (int iky = 0; iky < (py ? 2 : 3); ++iky)
+#pragma unroll
+        for (int ikx = 0; ikx < (px ? 2 : 3); ++ikx) {
+          const half8 af = s_w[T * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[2 - iky][2 - ikx][nt], acc[ph][nt], 0, 0, 0);
+          ++T;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // store: register q of a lane is channel (q&3) + 8(q>>2) + 4h; px = 0/1 of one output row go out as a pair
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (iy[nt] >= a.H || ix[nt] >= a.W) continue;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (c >= a.Cout) continue;
+      const float bias = a.bias[c];
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float2 v;
+        v.x = acc[2 * py][nt][q] + bias;
+        v.y = acc[2 * py + 1][nt][q] + bias;
+        if (a.clamp01) {
+          v.x = fminf(fmaxf(v.x, 0.f), 1.f);
+          v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+        }
+        float *dst = a.y_nchw + (((size_t)b * a.Cout + c) * a.Ho + 2 * iy[nt] + py) * a.Wo + 2 * ix[nt];
+        *reinterpret_cast<float2 *>(dst) = v;
+      }
+    }
+  }
+}
+
+int mfma_launch_deconv_fewch(const MfmaArgs &a0, hipStream_t s) {
+  using G = DeconvGeom<8, 32>;
+  constexpr int HALF = round_up(G::PH * G::RS, 32), BUF_GRAN = 2 * HALF + 25 * 64;
+  MfmaArgs a = a0;
+  a.tiles_x = cdiv(a.W, 32);
+  a.tiles_y = cdiv(a.H, 8);
+  const size_t lds = (size_t)2 * BUF_GRAN * 16;
+  auto kern = deconv5x5s2_fewch_kernel<2, 8, 32>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y < (1L << 31) && a.B <= 65535, "deconv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y, a.B), dim3(256), lds, s, a);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+}  // namespace licos

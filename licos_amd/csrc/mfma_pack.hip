@@ -240,6 +240,8 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
   a.Ho = 2 * H;
   a.Wo = 2 * W;
   a.clamp01 = clamp01;
+  if (MT == 1 && epilogue == EPI_NONE && y_nchw && ((uintptr_t)y_nchw & 7) == 0)
+    return mfma_launch_deconv_fewch(a, as_stream(stream));
   return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
 }
 

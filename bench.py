@@ -119,18 +119,22 @@ def main():
     stages = {}
     roof = None
     if events:
+        a3 = None
         for key, evs in events.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-            fl = stage_flops(*key) * B
-            stages["%s_%d_%d_%dx%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2)}
-        key = ("conv", 128, 128, 128, 128)
-        if key in events:
+            fl = stage_flops(*key[:5]) * key[5]
+            stages["%s_%d_%d_%dx%d_b%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
+            if key[:5] == ("conv", 128, 128, 128, 128) and (a3 is None or key[5] > a3[5]):
+                a3 = key
+        if a3 is not None:
+            key, LB = a3, a3[5]
             ms = sum(e0.elapsed_time(e1) for e0, e1 in events[key]) / len(events[key])
-            ach = FLOP_PER_TILE_A3 * B / (ms * 1e-3) / 1e12
+            ach = FLOP_PER_TILE_A3 * LB / (ms * 1e-3) / 1e12
             roof = {"kernel": "conv5x5s2_mfma_kernel<4,2,8,32,GDN> (g_a[2], 128->128 @128^2->64^2)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
-                    "launches": len(events[key]), "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * B}
+                    "launches": len(events[key]), "tiles_per_launch": LB,
+                    "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,6 +15,25 @@ from . import engine, ops
 
 _side_streams = {}
 
+# Optional host-side section timing (tools/profile_step.py): when a dict, every section boundary
+# synchronises the device and accumulates wall-clock seconds.  None in production.
+timings = None
+
+
+class _Section:
+    def __init__(self):
+        self.t = None
+
+    def mark(self, name):
+        if timings is None:
+            return
+        import time
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if self.t is not None:
+            timings[name] = timings.get(name, 0.0) + (now - self.t)
+        self.t = now
+
 
 def _side_stream(device):
     key = (device.type, device.index)
@@ -38,6 +57,8 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     med = eb.medians_vec()
+    sec = _Section()
+    sec.mark("c.start")
     sym = None
     keep = []  # every tensor the side stream touches stays referenced until the final sync
     shape = None
@@ -62,6 +83,7 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
     done = torch.cuda.Event()
     done.record(side)
     main.wait_event(done)
+    sec.mark("c.transforms+encode (device)")
     meta = torch.cat([t for (_, _, _, nw, st) in per_chunk for t in (nw, st)]).cpu().numpy()  # one D2H + sync
     counts = np.empty(B, dtype=np.int64)
     pos = 0
@@ -75,14 +97,18 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del keep, per_chunk
         return compress_fp16(net, x, chunk=chunk, cap_words=2 * nsym + 8)
+    sec.mark("c.lengths D2H")
     byte_off = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(counts * 4, out=byte_off[1:])
     off_dev = torch.from_numpy(byte_off).to(dev)
     packed = torch.empty(max(int(byte_off[-1]), 4), device=dev, dtype=torch.uint8)
     for (s0, n, words, nwords, _) in per_chunk:
         ops.rans_compact(words, nwords, off_dev, 0, out=packed, off_offset=s0)
+    sec.mark("c.compact")
     host = packed.cpu().numpy()
+    sec.mark("c.bytes D2H")
     strings = [host[byte_off[i]:byte_off[i + 1]].tobytes() for i in range(B)]
+    sec.mark("c.python bytes objects")
     return {"strings": [strings], "shape": torch.Size(shape)}
 
 
@@ -96,7 +122,10 @@ def decompress_fp16(net, strings, shape, chunk=1024):
     C = cdf.shape[0]
     h, w = int(shape[0]), int(shape[1])
     nsym, plane = C * h * w, h * w
+    sec = _Section()
+    sec.mark("d.start")
     data, byte_off = eb.pack_strings(strs, dev)
+    sec.mark("d.join + H2D")
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     med = eb.medians_vec()
@@ -123,6 +152,7 @@ def decompress_fp16(net, strings, shape, chunk=1024):
             torch.empty((n, C // 16, h, w, 16), device=dev, dtype=torch.float16)
         ops.eb_dequantize(sym, 1, B, med, n, C, h, w, want_nchw=False, blk16=y_blk, sym_offset=s0)
         engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+    sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
     return {"x_hat": x_hat}

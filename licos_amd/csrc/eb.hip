@@ -86,6 +86,62 @@ __global__ void eb_quantize_kernel(const float *__restrict__ y, const float *__r
   }
 }
 
+// Symbols in the coder's interleaved layout [position][stream]: a thread block owns 64 streams x 64
+// positions and transposes through LDS so that both the latent reads (contiguous along positions)
+// and the symbol writes (contiguous along streams) are coalesced.
+__global__ __launch_bounds__(256) void eb_symbols_T_kernel(const float *__restrict__ y, const float *__restrict__ medians,
+                                                           int32_t *__restrict__ symbols, long ssi, int B, int C, int HW) {
+  __shared__ int32_t tile[64][65];
+  const long n = (long)C * HW;
+  const long i0 = (long)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {  // r: stream within the tile, tx: position
+    const long i = i0 + tx;
+    const int b = b0 + r;
+    int32_t v = 0;
+    if (i < n && b < B) {
+      const int c = (int)(i / HW);
+      v = (int32_t)rintf(y[(size_t)b * n + i] - medians[c]);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {  // r: position, tx: stream
+    const long i = i0 + r;
+    const int b = b0 + tx;
+    if (i < n && b < B) symbols[i * ssi + b] = tile[tx][r];
+  }
+}
+
+// inverse: symbols [position][stream] -> y_hat as fp16 blk16 and/or NCHW fp32
+__global__ __launch_bounds__(256) void eb_dequantize_T_kernel(const int32_t *__restrict__ symbols, long ssi,
+                                                              const float *__restrict__ medians, float *__restrict__ y_nchw,
+                                                              _Float16 *__restrict__ y_blk, int B, int C, int HW) {
+  __shared__ int32_t tile[64][65];
+  const long n = (long)C * HW;
+  const long i0 = (long)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {  // r: position, tx: stream
+    const long i = i0 + r;
+    const int b = b0 + tx;
+    tile[r][tx] = (i < n && b < B) ? symbols[i * ssi + b] : 0;
+  }
+  __syncthreads();
+  const int C16 = (C + 15) / 16;
+  for (int r = ty; r < 64; r += 4) {  // r: stream, tx: position
+    const long i = i0 + tx;
+    const int b = b0 + r;
+    if (i < n && b < B) {
+      const int c = (int)(i / HW), p = (int)(i - (long)c * HW);
+      const float val = (float)tile[tx][r] + medians[c];
+      if (y_nchw) y_nchw[(size_t)b * n + i] = val;
+      if (y_blk) y_blk[(((size_t)b * C16 + (c >> 4)) * HW + p) * 16 + (c & 15)] = (_Float16)val;
+    }
+  }
+}
+
 // ---- likelihood -------------------------------------------------------------------------------
 __device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -259,6 +315,13 @@ int licos_eb_quantize(const float *y, const float *medians, const float *noise, 
   LICOS_REQUIRE(mode != 2 || symbols, "eb_quantize: symbols mode needs symbols");
   if (mode == 2) y_hat = nullptr;
   if (mode == 1) symbols = nullptr;
+  if (mode == 2 && ssb == 1 && B <= 65535 * 64) {
+    const long n = (long)C * HW;
+    hipLaunchKernelGGL(eb_symbols_T_kernel, dim3((unsigned)((n + 63) / 64), (B + 63) / 64), dim3(256), 0, as_stream(stream),
+                       y, medians, symbols, ssi, B, C, HW);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   const long total = (long)B * C * HW;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(eb_quantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, medians, noise, y_hat,
@@ -301,6 +364,13 @@ int licos_eb_likelihood(const float *v, const float *packed, const int *filters,
 int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float *medians, float *y_nchw,
                         void *y_blk16, int B, int C, int H, int W, void *stream) {
   LICOS_REQUIRE(symbols && medians && (y_nchw || y_blk16) && B > 0 && C > 0 && H > 0 && W > 0, "eb_dequantize: bad arguments");
+  if (ssb == 1 && B <= 65535 * 64) {
+    const long n = (long)C * H * W;
+    hipLaunchKernelGGL(eb_dequantize_T_kernel, dim3((unsigned)((n + 63) / 64), (B + 63) / 64), dim3(256), 0, as_stream(stream),
+                       symbols, ssi, medians, y_nchw, static_cast<_Float16 *>(y_blk16), B, C, H * W);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   const long total = (long)B * C * H * W;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(eb_dequantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), symbols, ssb, ssi, medians,

@@ -18,7 +18,7 @@ from .layers import GDN, conv_geometry
 _cache = weakref.WeakKeyDictionary()
 
 # Optional per-stage device timing (bench.py): when set to a dict, every stage launch is bracketed by
-# HIP events recorded on the stream the kernel is launched on; key = (kind, Cin, Cout, H, W).
+# HIP events recorded on the stream the kernel is launched on; key = (kind, Cin, Cout, H, W, tiles in the launch).
 stage_events = None
 
 
@@ -105,13 +105,13 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         gp = _packed_gdn(g) if g is not None else None
         if isinstance(m, nn.ConvTranspose2d):
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
-            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                           out_nchw=last, clamp01=clamp01 and last,
                                                           out=out if last else None))
         else:
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
-            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3])
+            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))
     return cur

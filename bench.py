@@ -48,10 +48,10 @@ def cpu_baseline(sd, cin, batch, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="tiles per GPU per step")
-    ap.add_argument("--chunk", type=int, default=1024, help="tiles per pipeline chunk inside a step")
+    ap.add_argument("--batch", type=int, default=8192, help="tiles per GPU per step")
+    ap.add_argument("--chunk", type=int, default=2048, help="tiles per pipeline chunk inside a step")
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--quality", type=int, default=3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
@@ -136,6 +136,26 @@ def main():
                     "launches": len(events[key]), "tiles_per_launch": LB,
                     "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB}
 
+    # federated weight averaging step: one RCCL all-reduce of the flat fp32 state
+    fed = None
+    if world > 1:
+        from licos_amd import federation
+        fs = federation.FlatState(net)
+        for _ in range(3):
+            federation.weighted_average_(fs, 1.0 / world)
+        fence()
+        t1 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            federation.weighted_average_(fs, 1.0 / world)
+        fence()
+        ft = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
+        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        nbytes_bucket = fs.flat.numel() * 4
+        fed = {"ms": round(1e3 * float(ft.item()), 4), "bucket_bytes": nbytes_bucket,
+               "busbw_GBps": round(2 * (world - 1) / world * nbytes_bucket / float(ft.item()) / 1e9, 2),
+               "what": "scale + RCCL all-reduce(SUM) + normalise of the whole floating state, per averaging step"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -155,7 +175,7 @@ def main():
                                    "module API, %d tiles per GPU per step" % (args.quality, args.channels, B),
                        "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": "synthetic trained-like (seeded)"},
             "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
-            "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+            "roofline": roof, "cpu_baseline": cpu, "fedavg_allreduce": fed, "stages": stages,
         }
         print(json.dumps(line))
     if world > 1:

@@ -149,6 +149,14 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/
                             int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int32_t *symbols,
                             int32_t *status, int B, void *stream);
 
+/* ------------------------------------------------------- federated averaging
+ * Replaces the file-based pair-wise blend of /root/reference/licos/federation_utils.py:47-53 by one
+ * collective over a flat fp32 bucket of the whole floating state: every rank scales its bucket by its
+ * coefficient (this kernel), RCCL all-reduces it (torch.distributed "nccl"), and the result is
+ * divided by the all-reduced coefficient sum carried in the bucket's last element.
+ * x[i] *= alpha for i < n;  alpha_dev (nullable): device pointer whose value is used as 1/(*alpha_dev). */
+int licos_scale_f32(float *x, long n, float alpha, const float *inv_alpha_dev, void *stream);
+
 /* ----------------------------------------------- 16-bit MFMA path (gfx950)
  * The fused hot path: 5x5 stride-2 Conv2d (+GDN) and ConvTranspose2d (+IGDN)
  * stages of CompressAI models/google.py FactorizedPrior.g_a / g_s

@@ -277,6 +277,11 @@ __global__ __launch_bounds__(256) void reduce_sqdiff_kernel(const float *__restr
   if (threadIdx.x == 0) atomicAdd(out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
+__global__ void scale_f32_kernel(float *__restrict__ x, long n, float alpha, const float *__restrict__ inv_alpha) {
+  const float a = inv_alpha ? alpha / inv_alpha[0] : alpha;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) x[e] *= a;
+}
+
 }  // namespace licos
 
 using namespace licos;
@@ -375,6 +380,14 @@ int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float 
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(eb_dequantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), symbols, ssb, ssi, medians,
                      y_nchw, static_cast<_Float16 *>(y_blk16), C, H, W, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_scale_f32(float *x, long n, float alpha, const float *inv_alpha_dev, void *stream) {
+  LICOS_REQUIRE(x && n > 0, "scale_f32: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, alpha, inv_alpha_dev);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

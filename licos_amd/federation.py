@@ -1,0 +1,123 @@
+"""Federated weight averaging over RCCL (xGMI), replacing the reference's file-based blend.
+
+Reference semantics (/root/reference/licos/federation_utils.py:9-85): when a rank
+"visits" the ground station it loads the central checkpoint, blends EVERY state_dict key as
+``w_l * local + w_c * central`` with ``w_l = best/(best+loss)``, ``w_c = loss/(best+loss)``
+(:47-53), overwrites the central file (:69-78) and adopts the blend (:85).  Visits are sequential
+and guarded by a lock file; no collective carries weights.
+
+Here the 8 satellites are the 8 GPUs of a node and reach the averaging point together, so the
+sequence of pair-wise blends for visit order 0..N-1 collapses to ONE convex combination
+``sum_r a_r * theta_r`` with ``a_0 = prod_{k>0} w_c,k`` and ``a_r = w_l,r * prod_{k>r} w_c,k``
+(`reference_coefficients`), computed by a single all-reduce of one flat fp32 bucket that holds the
+whole floating state (about 3.0 M elements, 12 MB) plus one element carrying the coefficient sum.
+Uniform coefficients give plain FedAvg.  Every rank ends with the central model (the reference
+leaves rank r with the central model *as of its visit*; documented difference).
+
+Integer buffers (the entropy coder's tables) are not averaged: blending them is the identity
+in exact arithmetic and a truncation hazard in floating point; call ``net.update(force=True)``
+after averaging to rebuild them from the averaged parameters.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatState:
+    """Re-homes every floating tensor of ``net.state_dict()`` into one contiguous fp32 bucket
+    (parameters and buffers become views of it), so averaging is a collective on one tensor and
+    the "load" afterwards is free.  One extra trailing element carries the coefficient."""
+
+    def __init__(self, net):
+        tensors = [(k, v) for k, v in net.state_dict(keep_vars=True).items() if v.dtype == torch.float32]
+        if not tensors:
+            raise ValueError("no floating state to average")
+        dev = tensors[0][1].device
+        total = sum(v.numel() for _, v in tensors)
+        self.flat = torch.empty(total + 1, device=dev, dtype=torch.float32)
+        self.keys = []
+        off = 0
+        with torch.no_grad():
+            for k, v in tensors:
+                n = v.numel()
+                view = self.flat[off:off + n].view(v.shape)
+                view.copy_(v.detach())
+                v.data = view  # parameter / buffer now lives inside the bucket
+                self.keys.append((k, off, n))
+                off += n
+            self.flat[-1] = 0.0
+        self.numel = total
+
+    def state(self):
+        return self.flat[: self.numel]
+
+
+def reference_coefficients(losses, best_losses):
+    """Closed form of the reference's sequential visits r = 0..N-1 (federation_utils.py:47-53)."""
+    n = len(losses)
+    wl = [b / (b + l) for b, l in zip(best_losses, losses)]
+    wc = [l / (b + l) for b, l in zip(best_losses, losses)]
+    coef = []
+    for r in range(n):
+        a = 1.0 if r == 0 else wl[r]
+        for k in range(r + 1, n):
+            a *= wc[k]
+        coef.append(a)
+    return coef
+
+
+def weighted_average_(flat_state, coef, group=None):
+    """In place: bucket <- sum_r coef_r * bucket_r / sum_r coef_r over the process group."""
+    flat = flat_state.flat
+    with torch.no_grad():
+        flat[-1] = 1.0
+        if flat.is_cuda:
+            ops.scale_f32(flat, coef)          # HIP kernel; last element becomes coef
+        else:
+            flat.mul_(coef)                    # gloo / CPU: only the collective logic is exercised here
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # "nccl" == RCCL over xGMI on ROCm
+        if flat.is_cuda:
+            ops.scale_f32(flat[: flat_state.numel], 1.0, inv_alpha_dev=flat[flat_state.numel:])
+        else:
+            flat[: flat_state.numel].div_(flat[-1])
+    return flat_state
+
+
+def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_time, cfg=None, flat_state=None,
+                         group=None, uniform=False):
+    """Collective counterpart of ``federation_utils.update_central_model`` (same leading arguments).
+    Every rank of the group must call it.  Returns the FlatState (reuse it on the next call)."""
+    if flat_state is None:
+        flat_state = FlatState(net)
+    loss = float(loss)
+    best_loss = float(best_loss)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if uniform or world == 1:
+        coef = 1.0
+    else:
+        mine = torch.tensor([loss, best_loss], dtype=torch.float64, device=flat_state.flat.device)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine, group=group)
+        vals = torch.stack(allv).cpu()
+        coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[dist.get_rank(group)]
+    weighted_average_(flat_state, coef, group=group)
+    return flat_state
+
+
+def clock_sync(running=1, group=None, device=None):
+    """The reference's ``comm.allreduce(1, op=MPI.SUM)`` + ``Barrier()`` liveness sync
+    (licos/main.py:96-107, :259-263): number of ranks still running."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return running
+    t = torch.tensor([running], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def shard_range(total, rank, world):
+    """Contiguous partition of `total` independent tiles over `world` ranks (no collective)."""
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)

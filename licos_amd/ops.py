@@ -197,6 +197,13 @@ def reduce_sqdiff(a, b, clamp01=False):
     return out
 
 
+def scale_f32(x, alpha, inv_alpha_dev=None):
+    """In place x *= alpha (or alpha / inv_alpha_dev[0])."""
+    _dev(x, inv_alpha_dev)
+    _lib.check(_lib.load().licos_scale_f32(_p(_f32(x)), x.numel(), float(alpha), _p(inv_alpha_dev), _stream()), "scale_f32")
+    return x
+
+
 # ----------------------------------------------------------------------------- rANS
 def rans_encode_batch(symbols, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, enc_table, cap_words,
                       batch, indexes=None, sym_offset=0):

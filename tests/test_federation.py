@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the collective weight average reproduces the reference's sequential
+file-based blend (licos/federation_utils.py:47-53) and tile sharding covers the batch exactly."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import licos_amd
+from licos_amd import federation
+from oracle import model as om
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, losses, best, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+        sd = om.perturb_state(om.make_factorized_state(3, 1, seed=rank), seed=rank)
+        net.load_state_dict(sd)
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        fs = federation.update_central_model(rank, "cpu", 0, net, losses[rank], best[rank], 0.0)
+        assert federation.clock_sync(1) == world
+        # parameters are views of the bucket: the module sees the averaged values without a load
+        after = {k: v.clone() for k, v in net.state_dict().items()}
+        torch.save({"before": before, "after": after, "numel": fs.numel}, out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weighted_allreduce_matches_sequential_blend(tmp_path):
+    world = 2
+    losses, best = [0.9, 0.6], [0.7, 0.6]
+    out = str(tmp_path / "r{rank}.pt")
+    mp.spawn(_worker, args=(world, _free_port(), losses, best, out), nprocs=world, join=True)
+    res = [torch.load(out.format(rank=r)) for r in range(world)]
+    float_keys = [k for k, v in res[0]["before"].items() if v.dtype == torch.float32]
+    ref = om.sequential_federation([{k: r["before"][k] for k in float_keys} for r in res], losses, best)
+    assert res[0]["numel"] == sum(res[0]["before"][k].numel() for k in float_keys)
+    for r in res:
+        for k in float_keys:
+            assert torch.allclose(r["after"][k], ref[k], rtol=1e-5, atol=1e-7), k
+        for k, v in r["before"].items():
+            if v.dtype != torch.float32:
+                assert torch.equal(r["after"][k], v)  # integer tables untouched
+
+
+def test_reference_coefficients_closed_form():
+    losses, best = [0.9, 0.7, 1.1, 0.6], [0.8, 0.7, 0.9, 0.5]
+    coef = federation.reference_coefficients(losses, best)
+    assert abs(sum(coef) - 1.0) < 1e-12
+    g = torch.Generator().manual_seed(0)
+    states = [{"w": torch.randn(64, generator=g)} for _ in range(4)]
+    ref = om.sequential_federation(states, losses, best)
+    got = sum(c * s["w"].double() for c, s in zip(coef, states))
+    assert torch.allclose(got, ref["w"].double(), atol=1e-6)
+
+
+@pytest.mark.parametrize("total,world", [(1024, 8), (1000, 8), (7, 8), (0, 2), (13, 4)])
+def test_shard_range_partitions_exactly(total, world):
+    covered = []
+    for r in range(world):
+        a, b = federation.shard_range(total, r, world)
+        assert 0 <= a <= b <= total
+        covered += list(range(a, b))
+    assert covered == list(range(total))
+    sizes = [federation.shard_range(total, r, world)[1] - federation.shard_range(total, r, world)[0] for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1

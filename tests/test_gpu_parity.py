@@ -311,3 +311,22 @@ def test_rans_plane_path_with_escapes(batch):
     assert strings == ref
     out = eb.decompress(strings, (4, 6))
     assert torch.equal(out.cpu(), om.eb_decompress(ref, (4, 6), sd))
+
+
+def test_flat_state_average_single_gpu():
+    """World size 1 on the GPU: the HIP scale kernels around the (absent) collective are an identity,
+    parameters live in the bucket, and the fp16 path picks the re-homed weights up."""
+    from licos_amd import federation
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=4)
+    net = _load(3, sd)
+    x = om.synthetic_tiles(1, 3, 64, seed=1).to(DEV)
+    with torch.no_grad():
+        y0 = net.g_a(x)
+        fs = federation.update_central_model(0, DEV, 0, net, 0.9, 0.7, 0.0)
+        assert net.g_a[0].weight.data_ptr() >= fs.flat.data_ptr()
+        y1 = net.g_a(x)
+        assert rel_err(y1, y0) < 1e-6
+        federation.weighted_average_(fs, 0.37)
+        y2 = net.g_a(x)
+    assert rel_err(y2, y0) < 1e-5
+    assert abs(float(fs.flat[-1]) - 0.37) < 1e-6

@@ -130,9 +130,15 @@ def main():
             key, LB = a3, a3[5]
             ms = sum(e0.elapsed_time(e1) for e0, e1 in events[key]) / len(events[key])
             ach = FLOP_PER_TILE_A3 * LB / (ms * 1e-3) / 1e12
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv_a3.json")
+            if os.path.exists(tfile):  # PMC passes cannot run inside the timed process; see profiles/README.md
+                tj = json.load(open(tfile))
+                traffic = tj["hbm_bytes_per_launch"] * LB / tj["tiles_per_launch"]
             roof = {"kernel": "conv5x5s2_mfma_kernel<4,2,8,32,GDN> (g_a[2], 128->128 @128^2->64^2)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_traffic_conv_a3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, scaled to this launch size)", "avg_launch_ms": round(ms, 4),
                     "launches": len(events[key]), "tiles_per_launch": LB,
                     "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB}
 

@@ -54,6 +54,23 @@ struct ConvStepGeom {
   static_assert(PATCH_GRAN % 64 == 0, "patch must be a whole number of wave-wide LDS-DMA pieces");
 };
 
+// XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8
+// XCDs, each with a private L2, so linear ids l and l+8 share an L2.  The grid is 1-D over B images x
+// `per_image` work items; this remap hands each XCD whole images (8 images in flight, one per XCD, their
+// items advancing together) so that tiles sharing halo rows - and the 4 output phases of a deconv tile,
+// which read the same patch and write the two halves of the same cache lines - meet in one L2.
+__device__ inline void xcd_work_item(int l, int B, int per_image, int &b, int &item) {
+  const int group = 8 * per_image;
+  const int g = l / group, r = l - g * group;
+  if ((g + 1) * 8 <= B) {
+    b = g * 8 + (r & 7);
+    item = r >> 3;
+  } else {  // tail group with fewer than 8 images: plain order
+    b = g * 8 + r / per_image;
+    item = r % per_image;
+  }
+}
+
 // 16 B global -> LDS without a register round trip: LDS address = wave-uniform base + lane * 16.
 __device__ inline void glds16(const void *gsrc, void *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,

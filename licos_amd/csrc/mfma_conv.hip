@@ -18,8 +18,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.y;
-  const int oy0 = (blockIdx.x / a.tiles_x) * TH, ox0 = (blockIdx.x % a.tiles_x) * TW;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
   const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
 
   int base[NT], oy[NT], ox[NT];
@@ -131,8 +132,8 @@ static int launch_conv(const MfmaArgs &a0, hipStream_t s) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y < (1L << 31) && a.B <= 65535, "conv5x5s2_f16: grid too large");
-  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y, a.B), dim3(256), lds, s, a);
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -19,8 +19,9 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.y;
-  const int phase = blockIdx.x & 3, tile = blockIdx.x >> 2;
+  int b, item;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y * 4, b, item);
+  const int phase = item & 3, tile = item >> 2;
   const int py = phase >> 1, px = phase & 1;
   const int nky = py ? 2 : 3, nkx = px ? 2 : 3, ntap = nky * nkx;
   const int phase_tap0 = (phase == 0) ? 0 : (phase == 1) ? 9 : (phase == 2) ? 15 : 21;
@@ -132,8 +133,8 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * 4 < (1L << 31) && a.B <= 65535, "deconv5x5s2_f16: grid too large");
-  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * 4, a.B), dim3(256), lds, s, a);
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * 4 * a.B < (1L << 31), "deconv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * 4 * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.y;
-  const int ty0 = (blockIdx.x / a.tiles_x) * TH, tx0 = (blockIdx.x % a.tiles_x) * TW;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
 
   int base[NT], iy[NT], ix[NT];
 #pragma unroll
@@ -315,8 +317,8 @@ int mfma_launch_deconv_fewch(const MfmaArgs &a0, hipStream_t s) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y < (1L << 31) && a.B <= 65535, "deconv5x5s2_f16: grid too large");
-  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y, a.B), dim3(256), lds, s, a);
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "deconv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

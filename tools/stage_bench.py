@@ -18,5 +18,5 @@ tot = 0
 for k, v in ev.items():
     ms = sum(a.elapsed_time(b) for a, b in v) / len(v)
     tot += ms
-    print("%-28s %8.3f ms" % ("%s_%d_%d_%dx%d" % k, ms))
+    print("%-28s %8.3f ms" % ("%s_%d_%d_%dx%d" % k[:5], ms))
 print("total %.3f ms for %d tiles -> %.1f us/tile" % (tot, B, 1e3 * tot / B))

@@ -178,29 +178,50 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const bool live = oy[nt] < a.Ho && ox[nt] < a.Wo && oy[nt] >= 0;
+      if (a.y_blk) {
+        // blk16: a 16-channel chunk of a pixel is 32 B.  A lane holds channels {0-3, 8-11} (+4 for the
+        // upper half-wave) of the chunk; one v_permlane32_swap per dword hands the lower lane channels
+        // 0-7 and the upper lane 8-15, so each lane stores ONE 16-byte piece (half as many stores).
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v[4];
+        for (int gp = 0; gp < 2; ++gp) {
+          unsigned lo[2], hi[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[it][nt][4 * g + e];
-          if (EPI != EPI_NONE) v[e] *= scale[nt][4 * g + e];
-          if (a.clamp01) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
-        }
-        const int c0 = 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
-        if (!live) continue;
-        if (a.y_blk) {
-          if (c0 < Cout16 * 16) {
-            half4 o;
+          for (int d = 0; d < 2; ++d) {
+            float v0[2], v1[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];  // padded channels carry zero weights and bias
-            _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + (c0 >> 4)) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + (c0 & 15);
-            *reinterpret_cast<half4 *>(dst) = o;
+            for (int e = 0; e < 2; ++e) {
+              v0[e] = acc[it][nt][8 * gp + 2 * d + e];
+              v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
+              if (EPI != EPI_NONE) {
+                v0[e] *= scale[nt][8 * gp + 2 * d + e];
+                v1[e] *= scale[nt][8 * gp + 4 + 2 * d + e];
+              }
+            }
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
+            lo[d] = __builtin_bit_cast(unsigned, p0);
+            hi[d] = __builtin_bit_cast(unsigned, p1);
+            const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+            lo[d] = sw[0];
+            hi[d] = sw[1];
           }
-        } else {
+          const int chunk = 2 * it + gp;
+          if (live && chunk < Cout16) {
+            _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + chunk) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + 8 * h;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+          }
+        }
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e < a.Cout) a.y_nchw[(((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt]] = v[e];
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[it][nt][4 * g + e];
+            if (EPI != EPI_NONE) v *= scale[nt][4 * g + e];
+            if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+            if (live && c0 + e < a.Cout) a.y_nchw[(((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt]] = v;
+          }
         }
       }
     }

@@ -42,6 +42,27 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+class PackedStrings(list):
+    """The list of per-tile byte strings ``compress`` returns, which also remembers the page-locked
+    host buffer the strings were cut from.  ``decompress`` uploads that buffer directly instead of
+    re-joining thousands of small byte objects (the strings themselves are ordinary ``bytes``)."""
+
+    def __init__(self, strings, packed_host, byte_off):
+        super().__init__(strings)
+        self.packed_host = packed_host  # pinned uint8 tensor
+        self.byte_off = byte_off        # np.int64 [B+1]
+
+    def still_packed(self):
+        if len(self) + 1 != self.byte_off.size:
+            return False
+        # cheap integrity check: lengths must still match the offsets (a caller may have edited the list)
+        n = len(self)
+        for i in (0, n // 2, n - 1):
+            if n and len(self[i]) != int(self.byte_off[i + 1] - self.byte_off[i]):
+                return False
+        return True
+
+
 def _chunks(total, size):
     return [(s, min(size, total - s)) for s in range(0, total, size)]
 
@@ -105,9 +126,13 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
     for (s0, n, words, nwords, _) in per_chunk:
         ops.rans_compact(words, nwords, off_dev, 0, out=packed, off_offset=s0)
     sec.mark("c.compact")
-    host = packed.cpu().numpy()
+    host_t = torch.empty(packed.numel(), dtype=torch.uint8, pin_memory=True)
+    host_t.copy_(packed, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    host = host_t.numpy()
     sec.mark("c.bytes D2H")
-    strings = [host[byte_off[i]:byte_off[i + 1]].tobytes() for i in range(B)]
+    mv = memoryview(host)
+    strings = PackedStrings([bytes(mv[byte_off[i]:byte_off[i + 1]]) for i in range(B)], host_t, byte_off)
     sec.mark("c.python bytes objects")
     return {"strings": [strings], "shape": torch.Size(shape)}
 
@@ -124,7 +149,12 @@ def decompress_fp16(net, strings, shape, chunk=1024):
     nsym, plane = C * h * w, h * w
     sec = _Section()
     sec.mark("d.start")
-    data, byte_off = eb.pack_strings(strs, dev)
+    if isinstance(strs, PackedStrings) and strs.still_packed():
+        total = int(strs.byte_off[-1])
+        data = strs.packed_host[:total].to(dev, non_blocking=True)
+        byte_off = torch.from_numpy(strs.byte_off).to(dev, non_blocking=True)
+    else:
+        data, byte_off = eb.pack_strings(strs, dev)
     sec.mark("d.join + H2D")
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)

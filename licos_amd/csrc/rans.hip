@@ -185,13 +185,23 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k)
         if (k < nb) sv[k] = sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi];
+      // table records for the whole batch first: they do not depend on the coder state, so the LDS
+      // latency stays off the serial x -> x chain below
+      EncRec rec[SYM_BATCH];
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k) {
+        if (k < nb) {
+          int32_t value = sv[k] - off;
+          value = (value < 0 || value >= max_value) ? max_value : value;
+          rec[k] = s_tab[value];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k) {
         if (k >= nb) break;
-        int32_t value = sv[k] - off;
+        const int32_t value = sv[k] - off;
         if (value < 0 || value >= max_value) {
           const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
-          value = max_value;
           int nbyp = 0;
           while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
           if (live) {
@@ -199,14 +209,13 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
             put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
           }
         }
-        const EncRec rec = s_tab[value];
-        const uint32_t freq = rec.freq ? rec.freq : 65536u;
+        const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
         if (x >= ((uint64_t)freq << 47)) {
           if (live) sink.put((uint32_t)x);
           x >>= 32;
         }
-        const uint64_t q = __umul64hi(x, rec.rcp) >> rec.shift;
-        x = x + rec.bias + q * (uint64_t)(65536u - freq);
+        const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
+        x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
       }
     }
   }
@@ -218,27 +227,43 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
   }
 }
 
-struct PrefetchSource {
+// Per-lane ring of the next stream words in LDS (16 slots, [slot][lane]) fed by 4-word loads that are
+// issued one refill EARLIER than they are written into the ring, so neither the renormalisation
+// (reads the ring) nor the refill (writes words that arrived long ago) ever waits on memory latency.
+struct RingSource {
   const uint32_t *p;
-  int nw, pos;  // pos = index of w0 in the stream
-  uint32_t w0, w1;
+  uint32_t *ring;  // LDS: word (i & 15) of this lane at ring[(i & 15) * 64]
+  int nw, rd, filled;
+  uint32_t pend[4];  // words filled .. filled+3, in flight
   bool over;
-  __device__ inline void init(const uint32_t *ptr, int n) {
-    p = ptr; nw = n; pos = 0; over = false;
-    w0 = (0 < nw) ? p[0] : 0u;
-    w1 = (1 < nw) ? p[1] : 0u;
+  __device__ inline uint32_t load_guarded(int i) const { return (i < nw) ? p[i] : 0u; }
+  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring) {
+    p = ptr; nw = n; ring = lane_ring; rd = 0; over = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ring[j * 64] = load_guarded(j);
+    filled = 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pend[j] = load_guarded(8 + j);
+  }
+  // call once per symbol: keeps >= 8 words buffered (a symbol consumes at most 4)
+  __device__ inline void refill() {
+    if (filled - rd <= 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ring[((filled + j) & 15) * 64] = pend[j];
+      filled += 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pend[j] = load_guarded(filled + j);
+    }
   }
   __device__ inline uint32_t next() {
-    if (pos >= nw) over = true;
-    const uint32_t r = w0;
-    w0 = w1;
-    w1 = (pos + 2 < nw) ? p[pos + 2] : 0u;
-    ++pos;
-    return r;
+    if (rd >= nw) over = true;
+    const uint32_t w = (rd < filled) ? ring[(rd & 15) * 64] : load_guarded(rd);  // second arm: malformed streams only
+    ++rd;
+    return w;
   }
 };
 
-__device__ inline uint32_t get_bits4p(uint64_t &x, PrefetchSource &src) {
+__device__ inline uint32_t get_bits4p(uint64_t &x, RingSource &src) {
   const uint32_t val = (uint32_t)(x & 15u);
   x >>= 4;
   if (x < RANS_L) x = (x << 32) | src.next();
@@ -253,16 +278,17 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
                                                                int32_t *__restrict__ symbols, int32_t *__restrict__ status,
                                                                int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(smem_raw);                   // [cdf_stride]
-  uint8_t *s_lut = reinterpret_cast<uint8_t *>(smem_raw) + (size_t)cdf_stride * 4;  // [256] when rows <= 256 entries
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [16][64] stream-word rings
+  uint32_t *s_cdf = s_ring + 16 * 64;                                         // [cdf_stride]
+  uint8_t *s_lut = reinterpret_cast<uint8_t *>(s_cdf) + (size_t)cdf_stride * 4;  // [256] when rows <= 256 entries
   uint16_t *s_lut16 = reinterpret_cast<uint16_t *>(s_lut);
   const bool wide = cdf_stride > 256;
   const int lane = threadIdx.x;
   const int b_raw = blockIdx.x * 64 + lane;
   const bool live = b_raw < B;
   const int b = live ? b_raw : B - 1;
-  PrefetchSource src;
-  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4));
+  RingSource src;
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane);
   uint64_t x = (uint64_t)src.next();
   x |= (uint64_t)src.next() << 32;
   int32_t *sp = symbols + (size_t)b * ssb;
@@ -285,6 +311,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
     }
     __syncthreads();
     for (int p = 0; p < plane; ++p) {
+      src.refill();
       const uint32_t cf = (uint32_t)(x & 0xFFFFu);
       int s = wide ? (int)s_lut16[cf >> 8] : (int)s_lut[cf >> 8];
       uint32_t lo = s_cdf[s], hi = s_cdf[s + 1];
@@ -354,8 +381,8 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  if (!indexes && n % plane == 0 && (size_t)cdf_stride * 4 + 512 <= 64 * 1024) {
-    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * 4 + 512,
+  if (!indexes && n % plane == 0 && (size_t)cdf_stride * 4 + 512 + 4096 <= 64 * 1024) {
+    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * 4 + 512 + 4096,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);
   } else {

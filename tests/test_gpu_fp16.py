@@ -142,3 +142,27 @@ def test_model_fp16_matches_oracle_rates(cin, kind):
     assert abs(nbytes16 - nbytes) < 0.01 * nbytes + 16
     # self-consistency: the decoder reproduces forward()'s reconstruction from the bytes alone
     assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
+
+
+def test_fp16_codec_accepts_plain_and_edited_string_lists():
+    """compress() returns a list subclass that remembers its packed host buffer; decompress must give the
+    same result for that object, for a plain list of the same bytes, and for a reordered plain list."""
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=11, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    net.chunk = 2  # 3 chunks for 5 tiles: exercises the pipeline seams and the ragged last chunk
+    x = om.synthetic_tiles(5, 3, 64, seed=8).to(DEV)
+    with torch.no_grad():
+        comp = net.compress(x)
+        a = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+        plain = [bytes(s) for s in comp["strings"][0]]
+        b = net.decompress([plain], comp["shape"])["x_hat"]
+        c = net.decompress([plain[::-1]], comp["shape"])["x_hat"]
+        net.chunk = 1024
+        d = net.decompress([plain], comp["shape"])["x_hat"]
+    assert torch.equal(a, b) and torch.equal(a, d)
+    assert torch.equal(a, c.flip(0))
+    assert all(isinstance(s, bytes) for s in comp["strings"][0])
+    assert np.frombuffer(np.array(comp["strings"]), dtype=np.uint8).size > 0  # eval_utils.py:202-204 idiom

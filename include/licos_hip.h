@@ -67,9 +67,11 @@ int licos_rans_build_enc_table(const int32_t *cdf_host, const int32_t *cdf_len_h
 /* ------------------------------------------------- 32-bit path (NCHW fp32)
  * torch.nn.Conv2d.forward as instantiated by CompressAI models/google.py
  * `conv()` and licos/model_utils.py:31-37.  Cross-correlation, square kernel. */
+#define LICOS_CONV_RELU 1      /* ReLU on the output (bmshj2018-factorized-relu, hyperprior h_a / h_s) */
+#define LICOS_CONV_ABS_INPUT 2 /* |x| on the input   (ScaleHyperprior: h_a(torch.abs(y)))              */
 int licos_conv2d_f32(const float *x, const float *w /*[Cout][Cin][K][K]*/, const float *bias /*nullable*/,
                      float *y, int B, int Cin, int H, int W, int Cout, int K, int stride, int pad,
-                     int relu, void *stream);
+                     int flags, void *stream);
 /* torch.nn.ConvTranspose2d.forward (CompressAI `deconv()`, licos/model_utils.py:38-45);
  * w is [Cin][Cout][K][K]; Hout = (H-1)*stride - 2*pad + K + out_pad. */
 int licos_deconv2d_f32(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H,
@@ -114,6 +116,17 @@ int licos_eb_likelihood(const float *v, const float *packed, const int *filters_
  * writes NCHW fp32 (nullable) and/or blk16 fp16 (nullable). */
 int licos_eb_dequantize(const int32_t *symbols, long sym_stride_b, long sym_stride_i, const float *medians,
                         float *y_hat_nchw, void *y_hat_blk16, int B, int C, int H, int W, void *stream);
+
+/* --------------------------------------------- Gaussian conditional (ScaleHyperprior, config 5)
+ * CompressAI entropy_models.py GaussianConditional._likelihood + LowerBound:
+ * s = max(scales, scale_bound); lik = max(Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), lik_bound), Phi(x) = erfc(-x/sqrt 2)/2.
+ * v, scales, lik: [B][C][HW] fp32; sum_log2 as in licos_eb_likelihood. */
+int licos_gc_likelihood(const float *v, const float *scales, float *lik, float scale_bound, float lik_bound,
+                        double *sum_log2, int B, int C, int HW, void *stream);
+/* GaussianConditional.build_indexes: idx = (levels-1) - #{t in table[:-1] : max(s, bound) <= t}; written in the
+ * coder's addressing (element (b, i) at b*stride_b + i*stride_i, i = c*HW + p). */
+int licos_gc_build_indexes(const float *scales, const float *table, int levels, float scale_bound, int32_t *indexes,
+                           long stride_b, long stride_i, int B, long n, void *stream);
 
 /* mean-squared-error numerator: sum over all elements of (a-b)^2 into *out (double, zeroed by caller);
  * /root/reference/eval_utils.py:145-156, RateDistortionLoss mse term.  clamp01 != 0 clamps `a` first. */

@@ -17,7 +17,9 @@ template <int K, int S>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ bias, float *__restrict__ y,
                                                          int Cin, int H, int W, int Cout, int Ho, int Wo, int pad,
-                                                         int tiles_x, int relu) {
+                                                         int tiles_x, int flags) {
+  const int relu = flags & LICOS_CONV_RELU;
+  const bool abs_in = flags & LICOS_CONV_ABS_INPUT;
   constexpr int PH = (TOH - 1) * S + K, PW = (TOW - 1) * S + K;
   __shared__ float s_x[CIB][PH][PW + 1];
   __shared__ __attribute__((aligned(16))) float s_w[CIB][K * K][COB];
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const float *__restrict
       const int iy = iy0 + r, ix = ix0 + q, ci = c0 + c;
       float v = 0.f;
       if (ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = xb[((size_t)ci * H + iy) * W + ix];
-      s_x[c][r][q] = v;
+      s_x[c][r][q] = abs_in ? fabsf(v) : v;
     }
     for (int e = tid; e < CIB * K * K * COB; e += 256) {
       const int j = e % COB, tap = (e / COB) % (K * K), c = e / (COB * K * K);
@@ -214,7 +216,7 @@ using namespace licos;
 extern "C" {
 
 int licos_conv2d_f32(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H, int W,
-                     int Cout, int K, int stride, int pad, int relu, void *stream) {
+                     int Cout, int K, int stride, int pad, int relu /* LICOS_CONV_* flags */, void *stream) {
   LICOS_REQUIRE(x && w && y, "conv2d_f32: NULL buffer");
   LICOS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d_f32: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   LICOS_REQUIRE(pad >= 0 && pad < K, "conv2d_f32: pad %d unsupported for K=%d", pad, K);

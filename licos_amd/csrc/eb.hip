@@ -277,6 +277,45 @@ __global__ __launch_bounds__(256) void reduce_sqdiff_kernel(const float *__restr
   if (threadIdx.x == 0) atomicAdd(out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
+// ---- Gaussian conditional ---------------------------------------------------------------------------
+__device__ inline float std_cumulative(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
+
+__global__ __launch_bounds__(256) void gc_likelihood_kernel(const float *__restrict__ v, const float *__restrict__ scales,
+                                                            float *__restrict__ lik, float scale_bound, float lik_bound,
+                                                            double *__restrict__ sum_log2, long per_image) {
+  __shared__ double s_red[4];
+  const int b = blockIdx.y;
+  double local = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per_image; e += (long)gridDim.x * blockDim.x) {
+    const size_t i = (size_t)b * per_image + e;
+    const float s = fmaxf(scales[i], scale_bound);
+    const float a = fabsf(v[i]);
+    float l = std_cumulative((0.5f - a) / s) - std_cumulative((-0.5f - a) / s);
+    l = fmaxf(l, lik_bound);
+    lik[i] = l;
+    local += (double)log2f(l);
+  }
+  if (sum_log2) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_red[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sum_log2[b], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  }
+}
+
+__global__ void gc_build_indexes_kernel(const float *__restrict__ scales, const float *__restrict__ table, int levels,
+                                        float scale_bound, int32_t *__restrict__ indexes, long sb, long si, long n,
+                                        long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / n, i = e - b * n;
+    const float s = fmaxf(scales[e], scale_bound);
+    int idx = levels - 1;
+    for (int t = 0; t < levels - 1; ++t) idx -= (s <= table[t]) ? 1 : 0;
+    indexes[b * sb + i * si] = idx;
+  }
+}
+
 __global__ void scale_f32_kernel(float *__restrict__ x, long n, float alpha, const float *__restrict__ inv_alpha) {
   const float a = inv_alpha ? alpha / inv_alpha[0] : alpha;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) x[e] *= a;
@@ -380,6 +419,28 @@ int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float 
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(eb_dequantize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), symbols, ssb, ssi, medians,
                      y_nchw, static_cast<_Float16 *>(y_blk16), C, H, W, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gc_likelihood(const float *v, const float *scales, float *lik, float scale_bound, float lik_bound,
+                        double *sum_log2, int B, int C, int HW, void *stream) {
+  LICOS_REQUIRE(v && scales && lik && B > 0 && B <= 65535 && C > 0 && HW > 0, "gc_likelihood: bad arguments");
+  const long per = (long)C * HW;
+  const int bx = (int)((per + 255) / 256 < 256 ? (per + 255) / 256 : 256);
+  hipLaunchKernelGGL(gc_likelihood_kernel, dim3(bx, B), dim3(256), 0, as_stream(stream), v, scales, lik, scale_bound,
+                     lik_bound, sum_log2, per);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gc_build_indexes(const float *scales, const float *table, int levels, float scale_bound, int32_t *indexes,
+                           long stride_b, long stride_i, int B, long n, void *stream) {
+  LICOS_REQUIRE(scales && table && indexes && levels > 0 && B > 0 && n > 0, "gc_build_indexes: bad arguments");
+  const long total = (long)B * n;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(gc_build_indexes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), scales, table, levels,
+                     scale_bound, indexes, stride_b, stride_i, n, total);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

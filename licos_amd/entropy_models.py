@@ -308,3 +308,145 @@ class EntropyBottleneck(nn.Module):
         if int(status.item()) != 0:
             raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
         return out
+
+
+class GaussianConditional(nn.Module):
+    """CompressAI ``GaussianConditional`` surface (scale hyperprior, BASELINE config 5): zero-mean Gaussian
+    with per-element scale, 64-level scale table, integer CDFs built on the host by ``update()``."""
+
+    def __init__(self, scale_table=None, *args, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9,
+                 entropy_coder_precision=16, **kwargs):
+        super().__init__()
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        self.lower_bound_scale = LowerBound(scale_bound)
+        self.register_buffer("scale_table", torch.Tensor() if scale_table is None else self._prepare(scale_table))
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self._coder_key = None
+        self._coder = None
+
+    @staticmethod
+    def _prepare(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name in ("_offset", "_quantized_cdf", "_cdf_length", "scale_table"):
+            k = prefix + name
+            if k in state_dict:
+                buf = getattr(self, name)
+                if buf.shape != state_dict[k].shape:
+                    setattr(self, name, torch.empty(state_dict[k].shape, dtype=buf.dtype, device=buf.device))
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._coder_key = None
+
+    def update_scale_table(self, scale_table, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.scale_table.device
+        self.scale_table = self._prepare(scale_table).to(dev)
+        self.update()
+        return True
+
+    def update(self):
+        from scipy.stats import norm
+        dev = self.scale_table.device
+        table = self.scale_table.detach().cpu().float()
+        multiplier = -norm.ppf(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(torch.max(pmf_length).item())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        scale = table.unsqueeze(1)
+        const = float(-(2 ** -0.5))
+        upper = 0.5 * torch.erfc(const * ((0.5 - samples) / scale))
+        lower = 0.5 * torch.erfc(const * ((-0.5 - samples) / scale))
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        cdf = np.zeros((len(pmf_length), max_length + 2), dtype=np.int32)
+        for i in range(len(pmf_length)):
+            prob = torch.cat((pmf[i, : pmf_length[i]], tail_mass[i]), dim=0).numpy()
+            row = ops.pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+            cdf[i, : row.size] = row
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._offset = (-pmf_center).to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._coder_key = None
+
+    coder_tables = EntropyBottleneck.coder_tables
+    _check_cdfs = EntropyBottleneck._check_cdfs
+
+    def forward(self, inputs, scales, means=None, training=None, noise=None, sum_log2=None):
+        if means is not None:
+            raise NotImplementedError("licos_amd: mean-scale variants are not built (SURVEY 8(f4))")
+        if training is None:
+            training = self.training
+        inputs = inputs.contiguous()
+        zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
+        if training:
+            if noise is None:
+                noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)
+            outputs = ops.eb_quantize(inputs, zeros, "noise", noise=noise.contiguous())
+        else:
+            outputs = ops.eb_quantize(inputs, zeros, "dequantize")
+        bound = self.likelihood_lower_bound.bound_value if self.use_likelihood_bound else 0.0
+        lik = ops.gc_likelihood(outputs, scales.contiguous(), self.lower_bound_scale.bound_value, bound, sum_log2)
+        return outputs, lik
+
+    def build_indexes_interleaved(self, scales):
+        """Table row per element in the coder's [position][stream] layout."""
+        b = scales.shape[0]
+        n = scales[0].numel()
+        idx = torch.empty((n, b), device=scales.device, dtype=torch.int32)
+        ops.gc_build_indexes(scales.contiguous(), self.scale_table, self.lower_bound_scale.bound_value, idx, 1, b)
+        return idx
+
+    def build_indexes(self, scales):
+        b = scales.shape[0]
+        return self.build_indexes_interleaved(scales).t().reshape(scales.shape).contiguous()
+
+    def compress(self, inputs, indexes_interleaved):
+        self._check_cdfs()
+        b = inputs.shape[0]
+        n = inputs[0].numel()
+        cdf, cdf_len, offset, table = self.coder_tables()
+        zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
+        sym = torch.empty((n, b), device=inputs.device, dtype=torch.int32)
+        ops.eb_quantize(inputs.contiguous(), zeros, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=b)
+        cap = n // 2 + 64
+        for attempt in range(2):
+            words, nwords, status = ops.rans_encode_batch(sym, 1, b, n, 0, cdf, cdf_len, offset, table, cap, b,
+                                                          indexes=indexes_interleaved)
+            host = torch.cat((nwords, status)).cpu().numpy()
+            if host[-1] == 0:
+                break
+            if attempt == 1:
+                raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
+            cap = 2 * n + 8
+        byte_off = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(host[:b].astype(np.int64) * 4, out=byte_off[1:])
+        packed = ops.rans_compact(words, nwords, torch.from_numpy(byte_off).to(sym.device), int(byte_off[-1]))
+        data = packed.cpu().numpy()
+        return [data[byte_off[i]:byte_off[i + 1]].tobytes() for i in range(b)]
+
+    def decompress(self, strings, indexes_interleaved, shape):
+        """shape: (C, H, W) of one latent; returns y_hat (B, C, H, W) fp32."""
+        self._check_cdfs()
+        b = len(strings)
+        c, h, w = shape
+        n = c * h * w
+        cdf, cdf_len, offset, _ = self.coder_tables()
+        data, byte_off = EntropyBottleneck.pack_strings(strings, cdf.device)
+        sym = torch.empty((n, b), device=cdf.device, dtype=torch.int32)
+        status = ops.rans_decode_batch(data, byte_off, 1, b, n, 0, cdf, cdf_len, offset, sym, b,
+                                       indexes=indexes_interleaved)
+        zeros = torch.zeros(c, device=cdf.device, dtype=torch.float32)
+        out = ops.eb_dequantize(sym, 1, b, zeros, b, c, h, w)
+        if int(status.item()) != 0:
+            raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+        return out

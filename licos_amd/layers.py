@@ -80,7 +80,7 @@ class GDN(nn.Module):
         return ops.gdn_f32(x.contiguous(), gamma, beta, self.inverse)
 
 
-def conv(in_channels, out_channels, kernel_size=5, stride=2):
+def conv(in_channels, out_channels, kernel_size=5, stride=2):  # noqa: E302 (CompressAI models/utils.py conv)
     return nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
 
 

@@ -18,7 +18,9 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .entropy_models import EntropyBottleneck
+import math
+
+from .entropy_models import EntropyBottleneck, GaussianConditional
 from .layers import GDN, conv, conv_geometry, deconv
 
 
@@ -26,9 +28,11 @@ class TransformSequential(nn.Sequential):
     """nn.Sequential whose forward runs the HIP transform pipeline."""
 
     precision = "fp32"
+    abs_input = False   # ScaleHyperprior.h_a consumes |y|
+    fp32_only = False   # hyper transforms (3x3 stride-1 stages) always run on the generic fp32 kernels
 
     def forward(self, x):
-        if self.precision == "fp16":
+        if self.precision == "fp16" and not self.fp32_only:
             from .engine import run_chain_fp16
             return run_chain_fp16(self, x)
         return run_chain_fp32(self, x)
@@ -40,15 +44,19 @@ def run_chain_fp32(seq, x):
     x = x.contiguous()
     mods = list(seq)
     i = 0
+    first = True
     while i < len(mods):
         m = mods[i]
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        abs_in = first and getattr(seq, "abs_input", False)
+        first = False
         if isinstance(m, nn.ConvTranspose2d):
             k, s, p, op = conv_geometry(m)
             x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
         elif isinstance(m, nn.Conv2d):
             k, s, p = conv_geometry(m)
-            x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu)
+            x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
+                               abs_input=abs_in)
         elif isinstance(m, GDN):
             x = m(x)
             relu = False
@@ -64,9 +72,11 @@ class CompressionModel(nn.Module):
     def aux_loss(self):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
 
-    def update(self, force=False):
+    def update(self, scale_table=None, force=False):
         updated = False
         for m in self.children():
+            if isinstance(m, GaussianConditional):
+                updated |= m.update_scale_table(get_scale_table() if scale_table is None else scale_table, force=force)
             if isinstance(m, EntropyBottleneck):
                 updated |= m.update(force=force)
         return updated
@@ -79,6 +89,11 @@ class CompressionModel(nn.Module):
             if isinstance(m, TransformSequential):
                 m.precision = precision
         return self
+
+
+def get_scale_table(min=0.11, max=256, levels=64):
+    """CompressAI models/google.py get_scale_table."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
 
 
 class FactorizedPrior(CompressionModel):
@@ -145,3 +160,67 @@ class FactorizedPriorReLU(FactorizedPrior):
                                        conv(N, N), nn.ReLU(inplace=True), conv(N, M))
         self.g_s = TransformSequential(deconv(M, N), nn.ReLU(inplace=True), deconv(N, N), nn.ReLU(inplace=True),
                                        deconv(N, N), nn.ReLU(inplace=True), deconv(N, 3))
+
+
+class ScaleHyperprior(CompressionModel):
+    """CompressAI ``ScaleHyperprior`` (bmshj2018-hyperprior, BASELINE config 5; allowed by
+    licos/model_utils.py:20-24).  g_a / g_s follow ``precision``; the small hyper transforms h_a / h_s
+    (3x3 stride-1 + 5x5 stride-2 stages on 1/16..1/64-resolution maps, < 3 % of the FLOPs) run on the
+    generic fp32 kernels in either mode."""
+
+    def __init__(self, N, M, precision="fp32", **kwargs):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.g_a = TransformSequential(conv(3, N), GDN(N), conv(N, N), GDN(N), conv(N, N), GDN(N), conv(N, M))
+        self.g_s = TransformSequential(deconv(M, N), GDN(N, inverse=True), deconv(N, N), GDN(N, inverse=True),
+                                       deconv(N, N), GDN(N, inverse=True), deconv(N, 3))
+        self.h_a = TransformSequential(conv(M, N, stride=1, kernel_size=3), nn.ReLU(inplace=True), conv(N, N),
+                                       nn.ReLU(inplace=True), conv(N, N))
+        self.h_a.abs_input = True
+        self.h_a.fp32_only = True
+        self.h_s = TransformSequential(deconv(N, N), nn.ReLU(inplace=True), deconv(N, N), nn.ReLU(inplace=True),
+                                       conv(N, M, stride=1, kernel_size=3), nn.ReLU(inplace=True))
+        self.h_s.fp32_only = True
+        self.gaussian_conditional = GaussianConditional(None)
+        self.N = int(N)
+        self.M = int(M)
+        self.precision = precision
+
+    @property
+    def downsampling_factor(self):
+        return 2 ** (4 + 2)
+
+    def _sync_precision(self):
+        self.g_a.precision = self.precision
+        self.g_s.precision = self.precision
+
+    def forward(self, x, noise=None):
+        self._sync_precision()
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_hat, z_likelihoods = self.entropy_bottleneck(z, noise=None if noise is None else noise.get("z"))
+        scales_hat = self.h_s(z_hat)
+        y_hat, y_likelihoods = self.gaussian_conditional(y, scales_hat, noise=None if noise is None else noise.get("y"))
+        x_hat = self.g_s(y_hat)
+        return {"x_hat": x_hat, "likelihoods": {"y": y_likelihoods, "z": z_likelihoods}}
+
+    def compress(self, x):
+        self._sync_precision()
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
+        scales_hat = self.h_s(z_hat)
+        indexes = self.gaussian_conditional.build_indexes_interleaved(scales_hat)
+        y_strings = self.gaussian_conditional.compress(y, indexes)
+        return {"strings": [y_strings, z_strings], "shape": z.size()[-2:]}
+
+    def decompress(self, strings, shape):
+        assert isinstance(strings, list) and len(strings) == 2
+        self._sync_precision()
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        scales_hat = self.h_s(z_hat)
+        indexes = self.gaussian_conditional.build_indexes_interleaved(scales_hat)
+        y_hat = self.gaussian_conditional.decompress(strings[0], indexes, tuple(scales_hat.shape[1:]))
+        x_hat = self.g_s(y_hat).clamp_(0, 1)
+        return {"x_hat": x_hat}

@@ -72,7 +72,7 @@ def query(device=0):
 
 
 # ----------------------------------------------------------------------------- 32-bit path
-def conv2d_f32(x, w, bias, stride, pad, relu=False):
+def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cout, cin_w, k, k2 = w.shape
@@ -81,7 +81,7 @@ def conv2d_f32(x, w, bias, stride, pad, relu=False):
     ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
     y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
     rc = _lib.load().licos_conv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride, pad,
-                                      int(relu), _stream())
+                                      int(bool(relu)) | (2 if abs_input else 0), _stream())
     _lib.check(rc, "conv2d_f32")
     return y
 
@@ -195,6 +195,27 @@ def reduce_sqdiff(a, b, clamp01=False):
     rc = _lib.load().licos_reduce_sqdiff(_p(_f32(a)), _p(_f32(b)), a.numel(), int(clamp01), _p(out), _stream())
     _lib.check(rc, "reduce_sqdiff")
     return out
+
+
+def gc_likelihood(v, scales, scale_bound, lik_bound, sum_log2=None):
+    _dev(v, scales, sum_log2)
+    b, c = v.shape[:2]
+    hw = v[0, 0].numel()
+    lik = torch.empty_like(v)
+    rc = _lib.load().licos_gc_likelihood(_p(_f32(v)), _p(_f32(scales)), _p(lik), scale_bound, lik_bound, _p(sum_log2),
+                                         b, c, hw, _stream())
+    _lib.check(rc, "gc_likelihood")
+    return lik
+
+
+def gc_build_indexes(scales, table, scale_bound, indexes, stride_b, stride_i):
+    _dev(scales, table, indexes)
+    b = scales.shape[0]
+    n = scales[0].numel()
+    rc = _lib.load().licos_gc_build_indexes(_p(_f32(scales)), _p(_f32(table)), table.numel(), scale_bound, _p(indexes),
+                                            stride_b, stride_i, b, n, _stream())
+    _lib.check(rc, "gc_build_indexes")
+    return indexes
 
 
 def scale_f32(x, alpha, inv_alpha_dev=None):

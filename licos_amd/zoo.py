@@ -3,7 +3,7 @@
 /root/reference/licos/model_utils.py:19 and licos/train.py:111-113 call.
 Topology per quality follows CompressAI ``zoo/image.py``: q1-5 -> (N, M) = (128, 192),
 q6-8 -> (192, 320)."""
-from .models import FactorizedPrior, FactorizedPriorReLU
+from .models import FactorizedPrior, FactorizedPriorReLU, ScaleHyperprior
 
 _CFGS = {q: ((128, 192) if q <= 5 else (192, 320)) for q in range(1, 9)}
 
@@ -27,7 +27,12 @@ def bmshj2018_factorized_relu(quality, metric="mse", pretrained=False, progress=
     return _load(FactorizedPriorReLU, "bmshj2018-factorized-relu", quality, pretrained, **kwargs)
 
 
+def bmshj2018_hyperprior(quality, metric="mse", pretrained=False, progress=True, **kwargs):
+    return _load(ScaleHyperprior, "bmshj2018-hyperprior", quality, pretrained, **kwargs)
+
+
 image_models = {
+    "bmshj2018-hyperprior": bmshj2018_hyperprior,
     "bmshj2018-factorized": bmshj2018_factorized,
     "bmshj2018-factorized-relu": bmshj2018_factorized_relu,
 }

@@ -106,7 +106,7 @@ def count_parameters(sd):
     n = 0
     for k, v in sd.items():
         leaf = k.split(".")[-1]
-        if leaf in ("pedestal", "bound", "target", "_offset", "_quantized_cdf", "_cdf_length"):
+        if leaf in ("pedestal", "bound", "target", "_offset", "_quantized_cdf", "_cdf_length", "scale_table", "scale_bound"):
             continue
         n += v.numel()
     return n
@@ -378,3 +378,142 @@ def perturb_state(sd, seed=7, y_gain=60.0, eb_init_scale=None):
     hi = 2.0 + 12.0 * torch.rand(c, generator=gen)
     sd["entropy_bottleneck.quantiles"] = torch.stack((med - lo, med, med + hi), dim=1).reshape(c, 1, 3)
     return sd
+
+
+# =========================================================================== ScaleHyperprior (config 5)
+# CompressAI models/google.py ScaleHyperprior, entropy_models.py GaussianConditional, zoo/image.py cfgs;
+# allowed by licos/model_utils.py:20-24 (EntropyBottleneck gets channels=N there).
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(mn=SCALES_MIN, mx=SCALES_MAX, levels=SCALES_LEVELS):
+    return torch.exp(torch.linspace(math.log(mn), math.log(mx), levels))
+
+
+def make_hyperprior_state(in_channels=3, quality=1, seed=42, eb_filters=None):
+    n, m = quality_to_nm(quality)
+    sd = make_factorized_state(in_channels, quality, seed, eb_filters=(3, 3, 3, 3))
+    for k in [k for k in sd if k.startswith("entropy_bottleneck.")]:
+        del sd[k]
+    gen = torch.Generator().manual_seed(seed + 1)
+    sd["h_a.0.weight"], sd["h_a.0.bias"] = _conv_init(n, m, 3, gen)
+    sd["h_a.2.weight"], sd["h_a.2.bias"] = _conv_init(n, n, 5, gen)
+    sd["h_a.4.weight"], sd["h_a.4.bias"] = _conv_init(n, n, 5, gen)
+    sd["h_s.0.weight"], sd["h_s.0.bias"] = _conv_init(n, n, 5, gen, transpose=True)
+    sd["h_s.2.weight"], sd["h_s.2.bias"] = _conv_init(n, n, 5, gen, transpose=True)
+    sd["h_s.4.weight"], sd["h_s.4.bias"] = _conv_init(m, n, 3, gen)
+    if eb_filters is None:
+        eb_filters = (in_channels, in_channels, 3, 3)
+    eb_init(sd, "entropy_bottleneck.", n, eb_filters, gen)
+    p = "gaussian_conditional."
+    sd[p + "scale_table"] = torch.zeros(0)
+    sd[p + "scale_bound"] = torch.tensor([SCALES_MIN])
+    sd[p + "lower_bound_scale.bound"] = torch.tensor([SCALES_MIN])
+    sd[p + "likelihood_lower_bound.bound"] = torch.tensor([LIKELIHOOD_BOUND])
+    sd[p + "_offset"] = torch.zeros(0, dtype=torch.int32)
+    sd[p + "_quantized_cdf"] = torch.zeros(0, dtype=torch.int32)
+    sd[p + "_cdf_length"] = torch.zeros(0, dtype=torch.int32)
+    return sd
+
+
+def h_a(y, sd):
+    z = F.relu(F.conv2d(torch.abs(y), sd["h_a.0.weight"], sd["h_a.0.bias"], stride=1, padding=1))
+    z = F.relu(F.conv2d(z, sd["h_a.2.weight"], sd["h_a.2.bias"], stride=2, padding=2))
+    return F.conv2d(z, sd["h_a.4.weight"], sd["h_a.4.bias"], stride=2, padding=2)
+
+
+def h_s(z, sd):
+    s = F.relu(F.conv_transpose2d(z, sd["h_s.0.weight"], sd["h_s.0.bias"], stride=2, padding=2, output_padding=1))
+    s = F.relu(F.conv_transpose2d(s, sd["h_s.2.weight"], sd["h_s.2.bias"], stride=2, padding=2, output_padding=1))
+    return F.relu(F.conv2d(s, sd["h_s.4.weight"], sd["h_s.4.bias"], stride=1, padding=1))
+
+
+def _std_cumulative(x):
+    return 0.5 * torch.erfc(-(2 ** -0.5) * x)
+
+
+def gc_update(sd, prefix="gaussian_conditional.", scale_table=None):
+    """GaussianConditional.update_scale_table + update()."""
+    from scipy.stats import norm
+    table = get_scale_table() if scale_table is None else scale_table
+    sd[prefix + "scale_table"] = table
+    multiplier = -norm.ppf(TAIL_MASS / 2)
+    pmf_center = torch.ceil(table * multiplier).int()
+    pmf_length = 2 * pmf_center + 1
+    max_length = int(torch.max(pmf_length).item())
+    samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+    scale = table.unsqueeze(1).float()
+    upper = _std_cumulative((0.5 - samples) / scale)
+    lower = _std_cumulative((-0.5 - samples) / scale)
+    pmf = upper - lower
+    tail_mass = 2 * lower[:, :1]
+    cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+    for i, p in enumerate(pmf):
+        prob = torch.cat((p[: pmf_length[i]], tail_mass[i]), dim=0)
+        c = rans.pmf_to_quantized_cdf(prob.numpy(), 16)
+        cdf[i, : c.size] = torch.from_numpy(c)
+    sd[prefix + "_quantized_cdf"] = cdf
+    sd[prefix + "_offset"] = -pmf_center
+    sd[prefix + "_cdf_length"] = (pmf_length + 2).int()
+
+
+def gc_likelihood(y_hat, scales, sd, prefix="gaussian_conditional."):
+    s = torch.max(scales, sd[prefix + "lower_bound_scale.bound"])
+    v = torch.abs(y_hat)
+    lik = _std_cumulative((0.5 - v) / s) - _std_cumulative((-0.5 - v) / s)
+    return torch.clamp(lik, min=float(sd[prefix + "likelihood_lower_bound.bound"]))
+
+
+def gc_build_indexes(scales, sd, prefix="gaussian_conditional."):
+    s = torch.max(scales, sd[prefix + "lower_bound_scale.bound"])
+    table = sd[prefix + "scale_table"]
+    idx = torch.full(s.shape, len(table) - 1, dtype=torch.int32)
+    for t in table[:-1]:
+        idx -= (s <= t).int()
+    return idx
+
+
+def hyper_update(sd, form="plain"):
+    gc_update(sd)
+    eb_update(sd, form=form)
+
+
+def hyper_forward(x, sd, form="plain"):
+    y = g_a(x, sd)
+    z = h_a(y, sd)
+    z_hat, z_lik = eb_forward(z, sd, form=form)
+    scales = h_s(z_hat, sd)
+    y_hat = torch.round(y)
+    y_lik = gc_likelihood(y_hat, scales, sd)
+    x_hat = g_s(y_hat, sd)
+    return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}, "y": y, "z": z, "scales": scales, "y_hat": y_hat,
+            "z_hat": z_hat}
+
+
+def hyper_compress(x, sd):
+    y = g_a(x, sd)
+    z = h_a(y, sd)
+    z_strings = eb_compress(z, sd)
+    z_hat = eb_decompress(z_strings, z.shape[-2:], sd)
+    scales = h_s(z_hat, sd)
+    idx = gc_build_indexes(scales, sd)
+    p = "gaussian_conditional."
+    sym = torch.round(y).int()
+    y_strings = [rans.encode_with_indexes(sym[i].reshape(-1).numpy(), idx[i].reshape(-1).numpy(),
+                                          sd[p + "_quantized_cdf"].numpy(), sd[p + "_cdf_length"].numpy(),
+                                          sd[p + "_offset"].numpy()) for i in range(y.shape[0])]
+    return {"strings": [y_strings, z_strings], "shape": tuple(z.shape[-2:])}
+
+
+def hyper_decompress(strings, shape, sd):
+    assert isinstance(strings, list) and len(strings) == 2
+    z_hat = eb_decompress(strings[1], shape, sd)
+    scales = h_s(z_hat, sd)
+    idx = gc_build_indexes(scales, sd)
+    p = "gaussian_conditional."
+    y_hat = torch.empty(scales.shape)
+    for i, s in enumerate(strings[0]):
+        v = rans.decode_with_indexes(s, idx[i].reshape(-1).numpy(), sd[p + "_quantized_cdf"].numpy(),
+                                     sd[p + "_cdf_length"].numpy(), sd[p + "_offset"].numpy())
+        y_hat[i] = torch.from_numpy(v).reshape(scales.shape[1:]).float()
+    return {"x_hat": g_s(y_hat, sd).clamp_(0, 1)}

@@ -160,3 +160,26 @@ def test_aux_optimizer_split_and_loss_surface():
     ref = om.rate_distortion_loss(out, x, 1e-2)
     for k in ("loss", "mse_loss", "bpp_loss"):
         assert abs(float(res[k]) - float(ref[k])) < 1e-6
+
+
+def test_hyperprior_surface_and_tables():
+    """bmshj2018-hyperprior (BASELINE config 5): CompressAI's parameter count, state_dict keys, the LICOS
+    channel surgery (EB over N channels with (in,in,3,3) filters) and host-built tables == oracle."""
+    stock = licos_amd.image_models["bmshj2018-hyperprior"](quality=1, pretrained=False)
+    assert sum(p.numel() for p in stock.parameters()) == 5075843
+    net = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5)
+    sd = om.make_hyperprior_state(13, 5)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    assert net.entropy_bottleneck.channels == 128 and net.entropy_bottleneck.filters == (13, 13, 3, 3)
+    assert om.count_parameters(sd) == sum(p.numel() for p in net.parameters())
+    net.load_state_dict(sd)
+    assert net.update() is True and net.update() is False
+    om.hyper_update(sd)
+    for mod in ("gaussian_conditional", "entropy_bottleneck"):
+        for k in ("_quantized_cdf", "_cdf_length", "_offset"):
+            assert torch.equal(getattr(getattr(net, mod), k), sd[f"{mod}.{k}"]), (mod, k)
+    assert torch.allclose(net.gaussian_conditional.scale_table, om.get_scale_table())
+    # a checkpoint saved after update() reloads with its tables
+    net2 = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5)
+    net2.load_state_dict(net.state_dict())
+    assert torch.equal(net2.gaussian_conditional._quantized_cdf, net.gaussian_conditional._quantized_cdf)

@@ -208,15 +208,50 @@ class EntropyBottleneck(nn.Module):
         x = x.contiguous()
         if x.shape[1] != self.channels:
             raise ValueError(f"expected {self.channels} channels, got {x.shape[1]}")
-        if training:
-            if noise is None:
-                noise = torch.empty_like(x).uniform_(-0.5, 0.5)
-            outputs = ops.eb_quantize(x, self.medians_vec(), "noise", noise=noise.contiguous())
-        else:
-            outputs = ops.eb_quantize(x, self.medians_vec(), "dequantize")
         bound = self.likelihood_lower_bound.bound_value if self.use_likelihood_bound else 0.0
-        lik = ops.eb_likelihood(outputs, self.packed_params(), self.filters, bound,
-                                0 if self.likelihood_form == "plain" else 1, sum_log2)
+        form = 0 if self.likelihood_form == "plain" else 1
+        if training and noise is None:
+            noise = torch.empty_like(x).uniform_(-0.5, 0.5)
+        from . import autograd
+        params = list(self.matrices) + list(self.biases) + list(self.factors)
+        if training and autograd.needs_grad(x, *params):
+            nl = len(self.filters) + 1
+            nz = noise.contiguous()
+
+            def hip(xx, *ps):
+                outs = ops.eb_quantize(xx.contiguous(), self.medians_vec(), "noise", noise=nz)
+                packed = ops.eb_pack(list(ps[:nl]), list(ps[nl:2 * nl]), list(ps[2 * nl:]), self.filters, self.channels)
+                return outs, ops.eb_likelihood(outs, packed, self.filters, bound, form, sum_log2)
+
+            def ref(xx, *ps):
+                outs = xx + nz
+                c = self.channels
+                v = outs.transpose(0, 1).reshape(c, 1, -1)
+
+                def logits(t):
+                    for i in range(nl):
+                        t = torch.matmul(F.softplus(ps[i]), t) + ps[nl + i]
+                        if i < nl - 1:
+                            t = t + torch.tanh(ps[2 * nl + i]) * torch.tanh(t)
+                    return t
+
+                lo, up = logits(v - 0.5), logits(v + 0.5)
+                if form == 0:
+                    lik = torch.sigmoid(up) - torch.sigmoid(lo)
+                else:
+                    sign = -torch.sign(lo + up).detach()
+                    lik = torch.abs(torch.sigmoid(sign * up) - torch.sigmoid(sign * lo))
+                if self.use_likelihood_bound:
+                    lik = autograd.lower_bound_ref(lik, self.likelihood_lower_bound.bound)
+                lik = lik.reshape(c, outs.shape[0], *outs.shape[2:]).transpose(0, 1)
+                return outs, lik
+
+            return autograd.HipForward.apply(hip, ref, x, *params)
+        if training:
+            outputs = ops.eb_quantize(x.detach(), self.medians_vec(), "noise", noise=noise.contiguous())
+        else:
+            outputs = ops.eb_quantize(x.detach(), self.medians_vec(), "dequantize")
+        lik = ops.eb_likelihood(outputs, self.packed_params(), self.filters, bound, form, sum_log2)
         return outputs, lik
 
     def _symbols_interleaved(self, x):

@@ -17,7 +17,7 @@ precision:
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 import math
 
 from .entropy_models import EntropyBottleneck, GaussianConditional
@@ -33,6 +33,9 @@ class TransformSequential(nn.Sequential):
 
     def forward(self, x):
         if self.precision == "fp16" and not self.fp32_only:
+            if autograd.needs_grad(x, *self.parameters()):
+                raise NotImplementedError("licos_amd: training (autograd) runs on precision='fp32'; the fp16 MFMA "
+                                          "path is inference-only (wrap evaluation in torch.no_grad())")
             from .engine import run_chain_fp16
             return run_chain_fp16(self, x)
         return run_chain_fp32(self, x)
@@ -52,11 +55,23 @@ def run_chain_fp32(seq, x):
         first = False
         if isinstance(m, nn.ConvTranspose2d):
             k, s, p, op = conv_geometry(m)
-            x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
+            if autograd.needs_grad(x, m.weight, m.bias):
+                args = (x, m.weight) if m.bias is None else (x, m.weight, m.bias)
+                x = autograd.HipForward.apply(
+                    lambda xx, ww, bb=None, s=s, p=p, op=op, relu=relu: ops.deconv2d_f32(xx.contiguous(), ww, bb, s, p, op, relu),
+                    autograd.deconv_ref(s, p, op, relu), *args)
+            else:
+                x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
         elif isinstance(m, nn.Conv2d):
             k, s, p = conv_geometry(m)
-            x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
-                               abs_input=abs_in)
+            if autograd.needs_grad(x, m.weight, m.bias):
+                args = (x, m.weight) if m.bias is None else (x, m.weight, m.bias)
+                x = autograd.HipForward.apply(
+                    lambda xx, ww, bb=None, s=s, p=p, relu=relu, a=abs_in: ops.conv2d_f32(xx.contiguous(), ww, bb, s, p, relu, abs_input=a),
+                    autograd.conv_ref(s, p, relu, abs_in), *args)
+            else:
+                x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
+                                   abs_input=abs_in)
         elif isinstance(m, GDN):
             x = m(x)
             relu = False

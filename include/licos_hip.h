@@ -192,6 +192,16 @@ int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float bet
 int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
 int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream);
 
+/* First analysis stage for few input channels (Cin <= 4: RGB, single Sentinel-2 band): a 5x5 stride-2 conv over
+ * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
+ * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the
+ * strided halo patch into a one-pixel halo.  H, W (even) are the ORIGINAL image size. */
+int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
+int licos_pack_conv_w_s2d_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, const float *bias,
+                            const void *gdn_packed, int epilogue, void *y_blk16, float *y_nchw, int B, int Cin,
+                            int H, int W, int Cout, void *stream);
+
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2

@@ -111,6 +111,7 @@ struct MfmaArgs {
   int Ho, Wo, Cout;       // output geometry; Cout = real channel count (<= 32*MT)
   int tiles_x, tiles_y;
   int clamp01;
+  int s1conv;             // deconv kernel used as a 3x3 stride-1 conv (space-to-depth first stage): one 'phase', no upsampling
   const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
 };
 

@@ -20,8 +20,8 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   int b, item;
-  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y * 4, b, item);
-  const int phase = item & 3, tile = item >> 2;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4), b, item);
+  const int phase = a.s1conv ? 0 : (item & 3), tile = a.s1conv ? item : (item >> 2);
   const int py = phase >> 1, px = phase & 1;
   const int nky = py ? 2 : 3, nkx = px ? 2 : 3, ntap = nky * nkx;
   const int phase_tap0 = (phase == 0) ? 0 : (phase == 1) ? 9 : (phase == 2) ? 15 : 21;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_mfma_kernel(MfmaArgs a) {
     const int p = (wave * NT + nt) * 32 + r;
     const int ty = p / TW, tx = p % TW;
     const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W;
-    oy[nt] = in ? 2 * (ty0 + ty) + py : -1;
-    ox[nt] = 2 * (tx0 + tx) + px;
+    oy[nt] = in ? (a.s1conv ? ty0 + ty : 2 * (ty0 + ty) + py) : -1;
+    ox[nt] = a.s1conv ? tx0 + tx : 2 * (tx0 + tx) + px;
     base[nt] = h * G::HALF + ty * G::RS + (tx + 1);
   }
   f32x16 acc[MT][NT];
@@ -133,8 +133,9 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * 4 * a.B < (1L << 31), "deconv5x5s2_f16: grid too large");
-  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * 4 * a.B), dim3(256), lds, s, a);
+  const long blocks = (long)a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4) * a.B;
+  LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -76,6 +76,47 @@ __global__ void pack_gdn_kernel(const float *__restrict__ beta_raw, const float 
   }
 }
 
+// space-to-depth conv weights: [Cout][Cin][5][5] -> phase-0-style fragments [cc][t = iky*3+ikx][mt][lane][8] of the
+// equivalent 3x3 stride-1 conv over channels c*4 + py*2 + px (see licos_conv5x5s2_s2d_f16)
+__global__ void pack_conv_w_s2d_kernel(const float *__restrict__ w, int Cin, int Cout, int C16, int MT,
+                                       _Float16 *__restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int mt = (int)(rest % MT); rest /= MT;
+    const int t = (int)(rest % 9), cc = (int)(rest / 9);
+    const int co = 32 * mt + (lane & 31), kidx = 16 * cc + 8 * (lane >> 5) + j;
+    const int c = kidx >> 2, py = (kidx >> 1) & 1, px = kidx & 1;
+    const int dy = 1 - t / 3, dx = 1 - t % 3;
+    const int ky = 2 * dy + 2 + py, kx = 2 * dx + 2 + px;
+    float v = 0.f;
+    if (co < Cout && c < Cin && ky <= 4 && kx <= 4) v = w[((size_t)co * Cin + c) * 25 + ky * 5 + kx];
+    out[e] = (_Float16)v;
+  }
+}
+
+// NCHW fp32 -> 2x2 space-to-depth blk16: out[b][chunk][y/2][x/2][k], k = c*4 + (y&1)*2 + (x&1)
+__global__ void nchw_to_s2d_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int C16, int H,
+                                         int W, long total) {
+  const int H2 = H / 2, W2 = W / 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int x2 = (int)(e % W2);
+    const int y2 = (int)((e / W2) % H2);
+    const int cc = (int)((e / ((long)W2 * H2)) % C16);
+    const long b = e / ((long)W2 * H2 * C16);
+    half8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kidx = cc * 16 + j, c = kidx >> 2, py = (kidx >> 1) & 1, px = kidx & 1;
+      const float v = (c < C) ? x[(((size_t)b * C + c) * H + 2 * y2 + py) * W + 2 * x2 + px] : 0.f;
+      if (j < 8) lo[j] = (_Float16)v; else hi[j - 8] = (_Float16)v;
+    }
+    half8 *dst = reinterpret_cast<half8 *>(y + (size_t)e * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
 __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int C16, long HW,
                                      long total) {
   // one thread per (b, chunk, pixel): writes 16 halfs (32 B)
@@ -158,6 +199,27 @@ int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float bet
   return LICOS_OK;
 }
 
+int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
+  LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "nchw_f32_to_s2d_blk16: bad arguments (H, W must be even)");
+  const int C16 = (4 * C + 15) / 16;
+  const long total = (long)B * C16 * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(nchw_to_s2d_blk16_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,
+                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), C, C16, H, W, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_pack_conv_w_s2d_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
+  const int MT = mt_for(Cout);
+  LICOS_REQUIRE(w && packed && Cin > 0 && MT > 0, "pack_conv_w_s2d_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  const int C16 = (4 * Cin + 15) / 16;
+  const long total = (long)C16 * 9 * MT * 512;
+  hipLaunchKernelGGL(pack_conv_w_s2d_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                     as_stream(stream), w, Cin, Cout, C16, MT, static_cast<_Float16 *>(packed), total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
   LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_blk16: bad arguments");
   const int C16 = (C + 15) / 16;
@@ -212,6 +274,7 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   a.W = W;
   a.Cout = Cout;
   a.clamp01 = 0;
+  a.s1conv = 0;
   a.zero16 = zero_page();
   LICOS_REQUIRE(a.zero16 != nullptr, "%s: could not allocate the zero page", who);
   *MT_out = MT;
@@ -246,3 +309,17 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
 }
 
 }  // extern "C"
+
+extern "C" int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, const float *bias,
+                                       const void *gdn_packed, int epilogue, void *y_blk16, float *y_nchw, int B, int Cin,
+                                       int H, int W, int Cout, void *stream) {
+  LICOS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv5x5s2_s2d_f16: H and W must be even");
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_s2d_blk16, w_packed_s2d, bias, gdn_packed, epilogue, y_blk16, y_nchw, B, 4 * Cin, H / 2, W / 2, Cout, &MT, "conv5x5s2_s2d_f16");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = H / 2;
+  a.Wo = W / 2;
+  a.s1conv = 1;  // 3x3 stride-1 taps = output phase (0,0) of the transposed-conv kernel without the upsampling
+  return mfma_dispatch_deconv(a, MT, epilogue, W / 2, as_stream(stream));
+}

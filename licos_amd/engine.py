@@ -38,8 +38,8 @@ def _pver(p):
     return None if p is None else (p.data_ptr(), p._version, str(p.device))
 
 
-def _packed_conv(m):
-    key = (_pver(m.weight), _pver(m.bias))
+def _packed_conv(m, s2d=False):
+    key = (_pver(m.weight), _pver(m.bias), s2d)
     ent = _cache.get(m)
     if ent is None or ent[0] != key:
         transposed = isinstance(m, nn.ConvTranspose2d)
@@ -48,7 +48,7 @@ def _packed_conv(m):
             raise ValueError("licos_amd: the fp16 MFMA path implements kernel 5 / stride 2 / padding 2 "
                              "(output_padding 1) stages only; use precision='fp32' for other shapes")
         cout = m.out_channels
-        wp = ops.pack_conv_w_f16(m.weight.detach(), transposed=transposed)
+        wp = ops.pack_conv_w_s2d_f16(m.weight.detach()) if s2d else ops.pack_conv_w_f16(m.weight.detach(), transposed=transposed)
         bp = ops.pad_bias(m.bias, cout, m.weight.device)
         ent = (key, wp, bp)
         _cache[m] = ent
@@ -91,18 +91,29 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
     """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32
     (written into `out` when given)."""
     st = stages(seq)
+    s2d_first = False
     if x_blk is None:
         if x.dtype != torch.float32:
             raise ValueError("licos_amd: inputs must be float32")
         if x.shape[1] != st[0][0].in_channels:
             raise ValueError(f"expected {st[0][0].in_channels} input channels, got {x.shape[1]}")
-        cur = ops.nchw_f32_to_blk16(x.contiguous())
+        h0, w0 = x.shape[2], x.shape[3]
+        # few input channels: 5x5 s2 over C == 3x3 s1 over the 4C channels of the 2x2 space-to-depth image
+        s2d_first = (isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
+                     and x.shape[1] <= 4 and h0 % 2 == 0 and w0 % 2 == 0)
+        cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous())
     else:
         cur = x_blk
     for idx, (m, g) in enumerate(st):
         last = idx == len(st) - 1
-        wp, bp = _packed_conv(m)
+        wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0))
         gp = _packed_gdn(g) if g is not None else None
+        if s2d_first and idx == 0:
+            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
+            key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0])
+            cur = _timed(key, lambda: ops.conv5x5s2_s2d_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, h0, w0,
+                                                            out_nchw=last, out=out if last else None))
+            continue
         if isinstance(m, nn.ConvTranspose2d):
             epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])

@@ -379,3 +379,38 @@ def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cou
                                            _p(yn), int(clamp01), b, cin, h, w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_f16")
     return y
+
+
+def nchw_f32_to_s2d_blk16(x):
+    _dev(x)
+    b, c, h, w = x.shape
+    y = torch.empty((b, (4 * c + 15) // 16, h // 2, w // 2, 16), device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_nchw_f32_to_s2d_blk16(_p(_f32(x)), _p(y), b, c, h, w, _stream()), "nchw_f32_to_s2d_blk16")
+    return y
+
+
+def pack_conv_w_s2d_f16(w):
+    _dev(w)
+    cout, cin = w.shape[:2]
+    mt = mfma_tiles(cout)
+    packed = torch.empty(((4 * cin + 15) // 16) * 9 * mt * 512, device=w.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_pack_conv_w_s2d_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
+               "pack_conv_w_s2d_f16")
+    return packed
+
+
+def conv5x5s2_s2d_f16(x_s2d, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, h, w, out_nchw=False, out=None):
+    """h, w: ORIGINAL (even) image size; x_s2d from nchw_f32_to_s2d_blk16."""
+    _dev(x_s2d, w_packed, bias_padded, gdn_packed, out)
+    b = x_s2d.shape[0]
+    ho, wo = h // 2, w // 2
+    if out_nchw:
+        y = _out_nchw(out, (b, cout, ho, wo), x_s2d.device)
+        yb, yn = None, y
+    else:
+        y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_s2d.device, dtype=torch.float16)
+        yb, yn = y, None
+    rc = _lib.load().licos_conv5x5s2_s2d_f16(_p(x_s2d), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+                                             _p(yn), b, cin, h, w, cout, _stream())
+    _lib.check(rc, "conv5x5s2_s2d_f16")
+    return y

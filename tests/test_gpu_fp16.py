@@ -166,3 +166,19 @@ def test_fp16_codec_accepts_plain_and_edited_string_lists():
     assert torch.equal(a, c.flip(0))
     assert all(isinstance(s, bytes) for s in comp["strings"][0])
     assert np.frombuffer(np.array(comp["strings"]), dtype=np.uint8).size > 0  # eval_utils.py:202-204 idiom
+
+
+@pytest.mark.parametrize("cin,h,w", [(3, 64, 64), (1, 32, 48), (3, 256, 256), (4, 18, 70), (2, 16, 16)])
+def test_first_stage_space_to_depth_equals_conv(cin, h, w):
+    """5x5 stride-2 conv over <=4 channels computed as a 3x3 stride-1 conv over the 2x2 space-to-depth image."""
+    g = torch.Generator().manual_seed(cin * 7 + h)
+    x = h16(torch.rand(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(128, cin, 5, 5, generator=g) * 0.2)
+    b = torch.randn(128, generator=g)
+    ref = F.conv2d(x, wt, b, stride=2, padding=2)
+    xs = ops.nchw_f32_to_s2d_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_s2d_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), 128, DEV)
+    out = ops.conv5x5s2_s2d_f16(xs, wp, bp, None, ops.EPI_NONE, cin, 128, h, w, out_nchw=True)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5

@@ -205,6 +205,7 @@ int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, c
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2
+#define LICOS_EPI_RELU 3 /* bmshj2018-factorized-relu: ReLU in place of (I)GDN */
 /* x: blk16 [B][Cin16/16][H][W][16]; out: blk16 fp16 (y_blk16) or NCHW fp32 (y_nchw), exactly one non-NULL.
  * Cout_real <= Cout_packed: channels beyond Cout_real are not stored.  H, W are the INPUT size. */
 int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,

@@ -26,7 +26,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int EPI_NONE = LICOS_EPI_NONE, EPI_GDN = LICOS_EPI_GDN, EPI_IGDN = LICOS_EPI_IGDN;
+constexpr int EPI_NONE = LICOS_EPI_NONE, EPI_GDN = LICOS_EPI_GDN, EPI_IGDN = LICOS_EPI_IGDN, EPI_RELU = LICOS_EPI_RELU;
 
 __host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -139,7 +139,7 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
 #pragma unroll
   for (int it = 0; it < MT; ++it) {
     f32x16 scale[NT];
-    if (EPI != EPI_NONE) {
+    if (EPI == EPI_GDN || EPI == EPI_IGDN) {
       // norm tile `it` = beta + sum_jt sum_s gamma(it, jt, s) x sq(acc[jt], regs 8s..8s+7)
       f32x16 norm[NT];
 #pragma unroll
@@ -193,9 +193,13 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
             for (int e = 0; e < 2; ++e) {
               v0[e] = acc[it][nt][8 * gp + 2 * d + e];
               v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
-              if (EPI != EPI_NONE) {
+              if (EPI == EPI_GDN || EPI == EPI_IGDN) {
                 v0[e] *= scale[nt][8 * gp + 2 * d + e];
                 v1[e] *= scale[nt][8 * gp + 4 + 2 * d + e];
+              }
+              if (EPI == EPI_RELU) {
+                v0[e] = fmaxf(v0[e], 0.f);
+                v1[e] = fmaxf(v1[e], 0.f);
               }
             }
             typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -219,7 +223,8 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[it][nt][4 * g + e];
-            if (EPI != EPI_NONE) v *= scale[nt][4 * g + e];
+            if (EPI == EPI_GDN || EPI == EPI_IGDN) v *= scale[nt][4 * g + e];
+            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
             if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
             if (live && c0 + e < a.Cout) a.y_nchw[(((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt]] = v;
           }
@@ -234,6 +239,7 @@ static inline int mt_for(int Cout) {
   if (Cout <= 32) return 1;
   if (Cout <= 128) return 4;
   if (Cout <= 192) return 6;
+  if (Cout <= 320) return 10;  // q6-8 latents (M = 320)
   return 0;
 }
 

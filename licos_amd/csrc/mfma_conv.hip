@@ -10,7 +10,7 @@
 namespace licos {
 
 template <int MT, int NT, int TH, int TW, int EPI>
-__global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void conv5x5s2_mfma_kernel(MfmaArgs a) {
   using G = ConvStepGeom<MT, TH, TW>;
   static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_mfma_kernel(MfmaArgs a) {
     __builtin_amdgcn_s_barrier();
   }
   const bf16x8 *gam = a.gamma;
-  if (EPI != EPI_NONE) {
+  if (EPI == EPI_GDN || EPI == EPI_IGDN) {
     // gamma fragments are read by all 4 waves: stage them once in the (now free) LDS
     bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
     for (int g = tid; g < G::GAMMA_GRAN; g += 256) s_gamma[g] = a.gamma[g];
@@ -125,7 +125,8 @@ static int launch_conv(const MfmaArgs &a0, hipStream_t s) {
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.Wo, TW);
   a.tiles_y = cdiv(a.Ho, TH);
-  const size_t lds = G::LDS_BYTES;
+  // gamma fragments share the K-loop buffers' space; only (I)GDN epilogues need room for them
+  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)2 * G::BUF_GRAN * 16;
   auto kern = conv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -158,6 +159,9 @@ int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_
   if (MT == 6 && epi == EPI_NONE) return dispatch_tile<6, EPI_NONE>(a, width, s);
   if (MT == 6 && epi == EPI_GDN) return dispatch_tile<6, EPI_GDN>(a, width, s);
   if (MT == 6 && epi == EPI_IGDN) return dispatch_tile<6, EPI_IGDN>(a, width, s);
+  if (MT == 4 && epi == EPI_RELU) return dispatch_tile<4, EPI_RELU>(a, width, s);
+  if (MT == 6 && epi == EPI_RELU) return dispatch_tile<6, EPI_RELU>(a, width, s);
+  if (MT == 10 && epi == EPI_NONE) return dispatch_tile<10, EPI_NONE>(a, width, s);
   return fail(LICOS_EINVAL, "mfma conv: %d output channels with epilogue %d not instantiated", 32 * MT, epi);
 }
 

@@ -257,9 +257,9 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   LICOS_REQUIRE((y_blk != nullptr) != (y_nchw != nullptr), "%s: exactly one of y_blk16 / y_nchw must be given", who);
   LICOS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0, "%s: bad shape", who);
   const int MT = mt_for(Cout);
-  LICOS_REQUIRE(MT > 0 && Cout > 0, "%s: Cout=%d unsupported (max 192)", who, Cout);
-  LICOS_REQUIRE(epi == EPI_NONE || gdn, "%s: (I)GDN epilogue needs packed gamma/beta", who);
-  LICOS_REQUIRE(epi >= 0 && epi <= 2, "%s: bad epilogue %d", who, epi);
+  LICOS_REQUIRE(MT > 0 && Cout > 0, "%s: Cout=%d unsupported (max 320)", who, Cout);
+  LICOS_REQUIRE((epi != EPI_GDN && epi != EPI_IGDN) || gdn, "%s: (I)GDN epilogue needs packed gamma/beta", who);
+  LICOS_REQUIRE(epi >= 0 && epi <= 3, "%s: bad epilogue %d", who, epi);
   LICOS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)bias & 15) == 0, "%s: buffers must be 16-byte aligned", who);
   a.x = static_cast<const _Float16 *>(x);
   a.wp = static_cast<const half8 *>(wp);

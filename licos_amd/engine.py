@@ -80,6 +80,9 @@ def stages(seq):
             if g.in_channels != m.out_channels:
                 raise ValueError("licos_amd: GDN width does not match the preceding conv")
             i += 1
+        elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            g = "relu"
+            i += 1
         elif i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.Conv2d, nn.ConvTranspose2d)):
             raise TypeError(f"licos_amd: fp16 path does not fuse {type(mods[i + 1]).__name__}; use precision='fp32'")
         out.append((m, g))
@@ -107,21 +110,19 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
     for idx, (m, g) in enumerate(st):
         last = idx == len(st) - 1
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0))
-        gp = _packed_gdn(g) if g is not None else None
+        gp = _packed_gdn(g) if isinstance(g, GDN) else None
+        epi = ops.EPI_NONE if g is None else ops.EPI_RELU if g == "relu" else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
         if s2d_first and idx == 0:
-            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0])
             cur = _timed(key, lambda: ops.conv5x5s2_s2d_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, h0, w0,
                                                             out_nchw=last, out=out if last else None))
             continue
         if isinstance(m, nn.ConvTranspose2d):
-            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                           out_nchw=last, clamp01=clamp01 and last,
                                                           out=out if last else None))
         else:
-            epi = ops.EPI_NONE if g is None else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
             key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))

@@ -267,7 +267,7 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
 
 
 # ----------------------------------------------------------------------------- 16-bit MFMA path
-EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
+EPI_NONE, EPI_GDN, EPI_IGDN, EPI_RELU = 0, 1, 2, 3
 
 
 def mfma_tiles(cout):
@@ -278,7 +278,9 @@ def mfma_tiles(cout):
         return 4
     if cout <= 192:
         return 6
-    raise ValueError(f"licos_amd: the fp16 MFMA path supports at most 192 output channels, got {cout}")
+    if cout <= 320:
+        return 10
+    raise ValueError(f"licos_amd: the fp16 MFMA path supports at most 320 output channels, got {cout}")
 
 
 def pack_conv_w_f16(w, transposed=False):

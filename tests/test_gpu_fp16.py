@@ -182,3 +182,62 @@ def test_first_stage_space_to_depth_equals_conv(cin, h, w):
     out = ops.conv5x5s2_s2d_f16(xs, wp, bp, None, ops.EPI_NONE, cin, 128, h, w, out_nchw=True)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 2e-5
+
+
+def _relu_state(cin, seed):
+    """A factorized-relu state: the factorized state without the GDN entries."""
+    sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=seed, y_gain=20.0)
+    return {k: v for k, v in sd.items() if ".beta" not in k and ".gamma" not in k}
+
+
+def _relu_forward(x, sd):
+    y = x
+    for li in range(4):
+        y = F.conv2d(y, sd[f"g_a.{2 * li}.weight"], sd[f"g_a.{2 * li}.bias"], stride=2, padding=2)
+        if li < 3:
+            y = F.relu(y)
+    return y
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("fp16", 2e-3)])
+def test_factorized_relu_variant(precision, tol):
+    """bmshj2018-factorized-relu (allowed by licos/model_utils.py:20-24): ReLU fused as a conv flag (fp32) or
+    as the MFMA epilogue (fp16)."""
+    sd = _relu_state(3, 3)
+    net = licos_amd.get_model("bmshj2018-factorized-relu", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision(precision)
+    net.update(force=True)
+    x = om.synthetic_tiles(2, 3, 128, seed=5)
+    with torch.no_grad():
+        y = net.g_a(x.to(DEV))
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+        out = net(x.to(DEV))
+    assert rel_err(y, _relu_forward(x, sd)) < tol
+    assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
+
+
+def test_quality6_topology_fp16():
+    """q6-8: N = 192, M = 320 (CompressAI zoo cfgs): 6- and 10-tile accumulators, 20 cin chunks in g_s[0]."""
+    sd = om.perturb_state(om.make_factorized_state(3, quality=6, seed=42), seed=9, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 6)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    om.eb_update(sd)
+    x = om.synthetic_tiles(2, 3, 128, seed=1)
+    with torch.no_grad():
+        out = net(x.to(DEV))
+        y16 = net.g_a(x.to(DEV))
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+    ref = om.forward(x, sd)
+    assert tuple(y16.shape) == (2, 320, 8, 8)
+    assert rel_err(y16, ref["y"]) < 1e-2
+    assert abs(licos_amd.metrics.compute_bpp(out) - om.compute_bpp(ref)) < 0.01 * om.compute_bpp(ref)
+    assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
+    net.set_precision("fp32")
+    with torch.no_grad():
+        y32 = net.g_a(x.to(DEV))
+    assert rel_err(y32, ref["y"]) < 1e-5

@@ -202,6 +202,13 @@ int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, c
                             const void *gdn_packed, int epilogue, void *y_blk16, float *y_nchw, int B, int Cin,
                             int H, int W, int Cout, void *stream);
 
+/* Last synthesis stage (Cout <= 32, NCHW fp32 out): all four output phases per workgroup, weights stored compact
+ * (only ceil-pow2(Cout) rows per fragment).  CompressAI FactorizedPrior.g_s[6], replaced per licos/model_utils.py:38-45. */
+size_t licos_packed_deconv_w_fewch_bytes(int Cin, int Cout);
+int licos_pack_deconv_w_fewch_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch, const float *bias, float *y_nchw,
+                                int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
+
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2

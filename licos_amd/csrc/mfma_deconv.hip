@@ -177,11 +177,15 @@ int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStrea
 // input pixel, so it stores px = 0/1 as one 8-byte pair: fully coalesced rows.
 namespace licos {
 
-template <int NT, int TH, int TW>
+// Weight fragments are stored COMPACT: only the first RP (4/8/16/32 >= Cout) rows of each 32-row A fragment are
+// real, so TPP = 32 / RP taps share one 64-granule LDS-DMA piece (granule = piece*64 + half*32 + tap_in_piece*RP
+// + row); lanes holding rows >= RP use a zero operand.  For RGB that is 4 KB of weights per cin chunk, not 25.
+template <int NT, int TH, int TW, int RP>
 __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
   using G = DeconvGeom<TH, TW>;
   static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
-  constexpr int HALF = round_up(G::PH * G::RS, 32), PATCH_GRAN = 2 * HALF, BUF_GRAN = PATCH_GRAN + 25 * 64;
+  constexpr int TPP = 32 / RP, WP = (25 + TPP - 1) / TPP;  // taps per piece, weight pieces per chunk
+  constexpr int HALF = round_up(G::PH * G::RS, 32), PATCH_GRAN = 2 * HALF, BUF_GRAN = PATCH_GRAN + WP * 64;
   static_assert(PATCH_GRAN % 64 == 0, "patch must be whole LDS-DMA pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half8 *s_buf = reinterpret_cast<half8 *>(smem);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
   const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
-  constexpr int PQ = PATCH_GRAN / 64, NPP = (PQ + 3) / 4, NWP = (25 + 3) / 4;
+  constexpr int PQ = PATCH_GRAN / 64, NPP = (PQ + 3) / 4, NWP = (WP + 3) / 4;
   const half8 *p_src[NPP];
   bool p_ok[NPP];
 #pragma unroll
@@ -225,17 +229,6 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
     p_ok[i] = j < G::PH && q < G::PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
     p_src[i] = xb + ((ptrdiff_t)yy * a.W + xx) * 2 + hh;
   }
-  // weight piece T (one tap, phase-major order) of chunk cc sits at (tap0(phase) * Cin16 + cc * ntap(phase) + t) * 64
-  int w_mul[NWP], w_add[NWP];
-#pragma unroll
-  for (int i = 0; i < NWP; ++i) {
-    const int T = wave + 4 * i;
-    const int ph = T < 9 ? 0 : T < 15 ? 1 : T < 21 ? 2 : 3;
-    const int tap0 = ph == 0 ? 0 : ph == 1 ? 9 : ph == 2 ? 15 : 21;
-    const int ntap = ph == 0 ? 9 : ph == 3 ? 4 : 6;
-    w_mul[i] = ntap * 64;
-    w_add[i] = (tap0 * a.Cin16 + (T - tap0)) * 64 + lane;
-  }
   auto stage = [&](int cc, int buf) {
     half8 *dst = s_buf + buf * BUF_GRAN;
 #pragma unroll
@@ -245,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
-      const int T = wave + 4 * i;
-      if (T < 25) glds16(a.wp + (size_t)cc * w_mul[i] + w_add[i], dst + PATCH_GRAN + T * 64);
+      const int q = wave + 4 * i;
+      if (q < WP) glds16(a.wp + ((size_t)cc * WP + q) * 64 + lane, dst + PATCH_GRAN + q * 64);
     }
   };
 
@@ -274,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
       for (int iky = 0; iky < (py ? 2 : 3); ++iky)
 #pragma unroll
         for (int ikx = 0; ikx < (px ? 2 : 3); ++ikx) {
-          const half8 af = s_w[T * 64 + lane];
+          half8 af = s_w[(T / TPP) * 64 + h * 32 + (T % TPP) * RP + (r & (RP - 1))];
+          if (RP < 32 && r >= RP) af = half8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[2 - iky][2 - ikx][nt], acc[ph][nt], 0, 0, 0);
@@ -309,14 +303,16 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
   }
 }
 
-int mfma_launch_deconv_fewch(const MfmaArgs &a0, hipStream_t s) {
+template <int RP>
+static int launch_fewch(const MfmaArgs &a0, hipStream_t s) {
   using G = DeconvGeom<8, 32>;
-  constexpr int HALF = round_up(G::PH * G::RS, 32), BUF_GRAN = 2 * HALF + 25 * 64;
+  constexpr int TPP = 32 / RP, WP = (25 + TPP - 1) / TPP;
+  constexpr int HALF = round_up(G::PH * G::RS, 32), BUF_GRAN = 2 * HALF + WP * 64;
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.W, 32);
   a.tiles_y = cdiv(a.H, 8);
   const size_t lds = (size_t)2 * BUF_GRAN * 16;
-  auto kern = deconv5x5s2_fewch_kernel<2, 8, 32>;
+  auto kern = deconv5x5s2_fewch_kernel<2, 8, 32, RP>;
   static bool attr_set = false;
   if (!attr_set) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -326,6 +322,14 @@ int mfma_launch_deconv_fewch(const MfmaArgs &a0, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
+}
+
+// rows kept per weight fragment for `Cout` output channels (must match licos_pack_deconv_w_fewch_f16)
+int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s) {
+  if (a.Cout <= 4) return launch_fewch<4>(a, s);
+  if (a.Cout <= 8) return launch_fewch<8>(a, s);
+  if (a.Cout <= 16) return launch_fewch<16>(a, s);
+  return launch_fewch<32>(a, s);
 }
 
 }  // namespace licos

@@ -46,6 +46,33 @@ __global__ void pack_deconv_w_kernel(const float *__restrict__ w, int Cin, int C
   }
 }
 
+// compact deconv weights for the few-channel last stage: [cc][piece][half][tap in piece][row] x 8 halfs, taps in
+// phase-major order (the order deconv5x5s2_fewch_kernel walks them)
+__global__ void pack_deconv_w_fewch_kernel(const float *__restrict__ w, int Cin, int Cout, int Cin16, int RP,
+                                           _Float16 *__restrict__ out, long total) {
+  const int TPP = 32 / RP, WP = (25 + TPP - 1) / TPP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7);
+    long g = e >> 3;                       // granule
+    const int in_piece = (int)(g & 63);
+    g >>= 6;
+    const int piece = (int)(g % WP), cc = (int)(g / WP);
+    const int hh = in_piece >> 5, rem = in_piece & 31;
+    const int T = piece * TPP + rem / RP, row = rem % RP;
+    float v = 0.f;
+    if (T < 25) {
+      const int phase = T < 9 ? 0 : T < 15 ? 1 : T < 21 ? 2 : 3;
+      const int tap0 = phase == 0 ? 0 : phase == 1 ? 9 : phase == 2 ? 15 : 21;
+      const int py = phase >> 1, px = phase & 1, nkx = px ? 2 : 3;
+      const int t = T - tap0;
+      const int ky = py + 2 * (t / nkx), kx = px + 2 * (t % nkx);
+      const int ci = 16 * cc + 8 * hh + j;
+      if (row < Cout && ci < Cin) v = w[((size_t)ci * Cout + row) * 25 + ky * 5 + kx];
+    }
+    out[e] = (_Float16)v;
+  }
+}
+
 // GDN: gamma_eff = max(gamma, bound)^2 - pedestal as bf16 A-fragments, k-permuted for the
 // accumulator-as-B-operand product: element e of lane (r, h) of fragment (it, jt, s) is
 // gamma[32it + r][32jt + 16s + 8(e>>2) + 4h + (e&3)].  beta_eff (fp32, padded) follows.
@@ -181,6 +208,24 @@ int licos_pack_deconv_w_f16(const float *w, int Cin, int Cout, void *packed, voi
   return LICOS_OK;
 }
 
+static int fewch_rows(int Cout) { return Cout <= 4 ? 4 : Cout <= 8 ? 8 : Cout <= 16 ? 16 : 32; }
+
+size_t licos_packed_deconv_w_fewch_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cout > 32) return 0;
+  const int RP = fewch_rows(Cout), TPP = 32 / RP, WP = (25 + TPP - 1) / TPP;
+  return (size_t)((Cin + 15) / 16) * WP * 1024;
+}
+
+int licos_pack_deconv_w_fewch_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
+  LICOS_REQUIRE(w && packed && Cin > 0 && Cout > 0 && Cout <= 32, "pack_deconv_w_fewch_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  const int RP = fewch_rows(Cout), TPP = 32 / RP, WP = (25 + TPP - 1) / TPP, Cin16 = (Cin + 15) / 16;
+  const long total = (long)Cin16 * WP * 512;
+  hipLaunchKernelGGL(pack_deconv_w_fewch_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                     as_stream(stream), w, Cin, Cout, Cin16, RP, static_cast<_Float16 *>(packed), total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 size_t licos_packed_gdn_bytes(int C) {
   const int MT = mt_for(C);
   if (MT == 0) return 0;
@@ -303,8 +348,6 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
   a.Ho = 2 * H;
   a.Wo = 2 * W;
   a.clamp01 = clamp01;
-  if (MT == 1 && epilogue == EPI_NONE && y_nchw && ((uintptr_t)y_nchw & 7) == 0)
-    return mfma_launch_deconv_fewch(a, as_stream(stream));
   return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
 }
 
@@ -322,4 +365,18 @@ extern "C" int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_pa
   a.Wo = W / 2;
   a.s1conv = 1;  // 3x3 stride-1 taps = output phase (0,0) of the transposed-conv kernel without the upsampling
   return mfma_dispatch_deconv(a, MT, epilogue, W / 2, as_stream(stream));
+}
+
+extern "C" int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch, const float *bias, float *y_nchw,
+                                           int clamp01, int B, int Cin, int H, int W, int Cout, void *stream) {
+  LICOS_REQUIRE(Cout > 0 && Cout <= 32, "deconv5x5s2_fewch_f16: Cout=%d (this kernel is for <= 32 output channels)", Cout);
+  LICOS_REQUIRE(((uintptr_t)y_nchw & 7) == 0, "deconv5x5s2_fewch_f16: output must be 8-byte aligned");
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_blk16, w_packed_fewch, bias, nullptr, EPI_NONE, nullptr, y_nchw, B, Cin, H, W, Cout, &MT, "deconv5x5s2_fewch_f16");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = 2 * H;
+  a.Wo = 2 * W;
+  a.clamp01 = clamp01;
+  return mfma_launch_deconv_fewch(a, as_stream(stream));
 }

@@ -38,8 +38,8 @@ def _pver(p):
     return None if p is None else (p.data_ptr(), p._version, str(p.device))
 
 
-def _packed_conv(m, s2d=False):
-    key = (_pver(m.weight), _pver(m.bias), s2d)
+def _packed_conv(m, s2d=False, fewch=False):
+    key = (_pver(m.weight), _pver(m.bias), s2d, fewch)
     ent = _cache.get(m)
     if ent is None or ent[0] != key:
         transposed = isinstance(m, nn.ConvTranspose2d)
@@ -48,7 +48,12 @@ def _packed_conv(m, s2d=False):
             raise ValueError("licos_amd: the fp16 MFMA path implements kernel 5 / stride 2 / padding 2 "
                              "(output_padding 1) stages only; use precision='fp32' for other shapes")
         cout = m.out_channels
-        wp = ops.pack_conv_w_s2d_f16(m.weight.detach()) if s2d else ops.pack_conv_w_f16(m.weight.detach(), transposed=transposed)
+        if fewch:
+            wp = ops.pack_deconv_w_fewch_f16(m.weight.detach())
+        elif s2d:
+            wp = ops.pack_conv_w_s2d_f16(m.weight.detach())
+        else:
+            wp = ops.pack_conv_w_f16(m.weight.detach(), transposed=transposed)
         bp = ops.pad_bias(m.bias, cout, m.weight.device)
         ent = (key, wp, bp)
         _cache[m] = ent
@@ -109,7 +114,13 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         cur = x_blk
     for idx, (m, g) in enumerate(st):
         last = idx == len(st) - 1
-        wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0))
+        fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
+        wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
+        if fewch:
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            cur = _timed(key, lambda: ops.deconv5x5s2_fewch_f16(cur, wp, bp, m.in_channels, m.out_channels,
+                                                                clamp01=clamp01, out=out))
+            continue
         gp = _packed_gdn(g) if isinstance(g, GDN) else None
         epi = ops.EPI_NONE if g is None else ops.EPI_RELU if g == "relu" else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
         if s2d_first and idx == 0:

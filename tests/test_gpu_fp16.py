@@ -57,7 +57,8 @@ def test_conv_stage_exact_operands(cin, cout, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
-                                           (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19)])
+                                           (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19),
+                                           (128, 7, 9, 40), (192, 24, 8, 33)])
 def test_deconv_stage_exact_operands(cin, cout, h, w):
     g = torch.Generator().manual_seed(cin + cout + h)
     x = h16(torch.randn(2, cin, h, w, generator=g))
@@ -75,6 +76,12 @@ def test_deconv_stage_exact_operands(cin, cout, h, w):
         assert rel_err(ops.blk16_to_nchw_f32(outb, cout), ref) < 1e-3
     outc = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True, clamp01=True)
     assert rel_err(outc, ref.clamp(0, 1)) < 2e-5
+    if cout <= 32:  # the all-phase few-channel kernel with compact weights
+        wf = ops.pack_deconv_w_fewch_f16(wt.to(DEV))
+        outf = ops.deconv5x5s2_fewch_f16(xb, wf, bp, cin, cout)
+        assert rel_err(outf, ref) < 2e-5
+        outf = ops.deconv5x5s2_fewch_f16(xb, wf, bp, cin, cout, clamp01=True)
+        assert rel_err(outf, ref.clamp(0, 1)) < 2e-5
 
 
 @pytest.mark.parametrize("inverse", [False, True])

@@ -179,12 +179,20 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
     __syncthreads();
     for (int e = lane; e < len - 1; e += 64) s_tab[e] = table[(size_t)c * cdf_stride + e];
     __syncthreads();
+    // symbols are fetched one batch ahead, so their load latency hides under the coding of the current batch
+    int32_t sv_next[SYM_BATCH];
+    auto fetch = [&](int p1, int32_t (&dst)[SYM_BATCH]) {
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k)
+        dst[k] = (p1 - 1 - k >= 0) ? sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi] : 0;
+    };
+    fetch(plane, sv_next);
     for (int p1 = plane; p1 > 0; p1 -= SYM_BATCH) {
       const int nb = p1 < SYM_BATCH ? p1 : SYM_BATCH;
       int32_t sv[SYM_BATCH];
 #pragma unroll
-      for (int k = 0; k < SYM_BATCH; ++k)
-        if (k < nb) sv[k] = sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi];
+      for (int k = 0; k < SYM_BATCH; ++k) sv[k] = sv_next[k];
+      if (p1 - SYM_BATCH > 0) fetch(p1 - SYM_BATCH, sv_next);
       // table records for the whole batch first: they do not depend on the coder state, so the LDS
       // latency stays off the serial x -> x chain below
       EncRec rec[SYM_BATCH];
@@ -227,37 +235,41 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
   }
 }
 
-// Per-lane ring of the next stream words in LDS (16 slots, [slot][lane]) fed by 4-word loads that are
-// issued one refill EARLIER than they are written into the ring, so neither the renormalisation
-// (reads the ring) nor the refill (writes words that arrived long ago) ever waits on memory latency.
+// Per-lane ring of the next stream words in LDS (RING slots, [slot][lane]).  The serial loop itself issues
+// no global memory operation: when ANY lane runs low the whole wave tops its rings up together (all loads
+// issued before the first is consumed: one memory round trip per refill, and refills are rare - a stream
+// averages well under one word per symbol), and decoded symbols leave through a 16-deep LDS buffer.
+constexpr int RING = 64, RING_LOW = 16, SYM_BUF = 16;
+
 struct RingSource {
   const uint32_t *p;
-  uint32_t *ring;  // LDS: word (i & 15) of this lane at ring[(i & 15) * 64]
+  uint32_t *ring;  // LDS: word (i & (RING-1)) of this lane at ring[(i & (RING-1)) * 64]
   int nw, rd, filled;
-  uint32_t pend[4];  // words filled .. filled+3, in flight
   bool over;
   __device__ inline uint32_t load_guarded(int i) const { return (i < nw) ? p[i] : 0u; }
   __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring) {
-    p = ptr; nw = n; ring = lane_ring; rd = 0; over = false;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ring[j * 64] = load_guarded(j);
-    filled = 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pend[j] = load_guarded(8 + j);
+    p = ptr; nw = n; ring = lane_ring; rd = 0; over = false; filled = 0;
+    top_up();
+    top_up();
   }
-  // call once per symbol: keeps >= 8 words buffered (a symbol consumes at most 4)
-  __device__ inline void refill() {
-    if (filled - rd <= 8) {
+  // up to 16 more words for every lane that has room (uniform control flow, per-lane predication)
+  __device__ inline void top_up() {
+    uint32_t w[16];
+    const bool room = filled - rd <= RING - 16;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ring[((filled + j) & 15) * 64] = pend[j];
-      filled += 4;
+    for (int j = 0; j < 16; ++j) w[j] = room ? load_guarded(filled + j) : 0u;
+    if (room) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pend[j] = load_guarded(filled + j);
+      for (int j = 0; j < 16; ++j) ring[((filled + j) & (RING - 1)) * 64] = w[j];
+      filled += 16;
     }
+  }
+  __device__ inline void refill_if_low() {
+    if (__any(filled - rd <= RING_LOW)) top_up();
   }
   __device__ inline uint32_t next() {
     if (rd >= nw) over = true;
-    const uint32_t w = (rd < filled) ? ring[(rd & 15) * 64] : load_guarded(rd);  // second arm: malformed streams only
+    const uint32_t w = (rd < filled) ? ring[(rd & (RING - 1)) * 64] : 0u;  // rd >= filled only on malformed streams
     ++rd;
     return w;
   }
@@ -278,8 +290,9 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
                                                                int32_t *__restrict__ symbols, int32_t *__restrict__ status,
                                                                int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [16][64] stream-word rings
-  uint32_t *s_cdf = s_ring + 16 * 64;                                         // [cdf_stride]
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [RING][64] stream-word rings
+  int32_t *s_out = reinterpret_cast<int32_t *>(s_ring + RING * 64);           // [SYM_BUF][64] decoded symbols
+  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(s_out + SYM_BUF * 64);       // [cdf_stride]
   uint8_t *s_lut = reinterpret_cast<uint8_t *>(s_cdf) + (size_t)cdf_stride * 4;  // [256] when rows <= 256 entries
   uint16_t *s_lut16 = reinterpret_cast<uint16_t *>(s_lut);
   const bool wide = cdf_stride > 256;
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
     }
     __syncthreads();
     for (int p = 0; p < plane; ++p) {
-      src.refill();
+      src.refill_if_low();
       const uint32_t cf = (uint32_t)(x & 0xFFFFu);
       int s = wide ? (int)s_lut16[cf >> 8] : (int)s_lut[cf >> 8];
       uint32_t lo = s_cdf[s], hi = s_cdf[s + 1];
@@ -331,7 +344,12 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
         value = (int32_t)(raw >> 1);
         value = (raw & 1u) ? -value - 1 : value + max_value;
       }
-      if (live) sp[(size_t)((size_t)c * plane + p) * ssi] = value + off;
+      s_out[(p & (SYM_BUF - 1)) * 64 + lane] = value + off;
+      if ((p & (SYM_BUF - 1)) == SYM_BUF - 1 || p == plane - 1) {  // uniform: flush the buffered symbols
+        const int p0 = p & ~(SYM_BUF - 1);
+        if (live)
+          for (int k = 0; k <= p - p0; ++k) sp[(size_t)((size_t)c * plane + p0 + k) * ssi] = s_out[k * 64 + lane];
+      }
     }
   }
   if (live && src.over) atomicOr(status, 1);
@@ -381,8 +399,9 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  if (!indexes && n % plane == 0 && (size_t)cdf_stride * 4 + 512 + 4096 <= 64 * 1024) {
-    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * 4 + 512 + 4096,
+  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + (size_t)cdf_stride * 4 + 512;
+  if (!indexes && n % plane == 0 && dec_lds <= 64 * 1024) {
+    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);
   } else {

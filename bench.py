@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384, help="tiles per GPU per step")
-    ap.add_argument("--chunk", type=int, default=8192, help="tiles per pipeline chunk inside a step")
+    ap.add_argument("--chunk", type=int, default=4096, help="tiles per pipeline chunk inside a step")
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--quality", type=int, default=3)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])

@@ -5,15 +5,16 @@ tile, a few waves in total, a fixed ~N_symbols x chain-latency no matter how man
 The transforms are throughput-bound and fill the chip.  The two therefore overlap almost for free:
 the batch is cut into chunks; while the MFMA kernels of chunk k+1 run on the main stream, the coder
 kernel of chunk k runs on a side stream (encode), and symmetrically the decoder of chunk k+1 runs
-under the synthesis transform of chunk k.  One device->host hand-over of the stream lengths and one
-of the packed bytes per call; the byte strings are CompressAI's, one per tile.
+under the synthesis transform of chunk k.  The host side of a chunk (stream lengths, compaction, copy
+of the packed bytes into page-locked memory, building the per-tile ``bytes``) runs on a third stream
+while later chunks are still being transformed.  The byte strings are CompressAI's, one per tile.
 """
 import numpy as np
 import torch
 
 from . import engine, ops
 
-_side_streams = {}
+_streams = {}
 
 # Optional host-side section timing (tools/profile_step.py): when a dict, every section boundary
 # synchronises the device and accumulates wall-clock seconds.  None in production.
@@ -35,31 +36,31 @@ class _Section:
         self.t = now
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
+def _stream(device, role):
+    key = (device.type, device.index, role)
+    if key not in _streams:
+        _streams[key] = torch.cuda.Stream(device=device)
+    return _streams[key]
 
 
 class PackedStrings(list):
     """The list of per-tile byte strings ``compress`` returns, which also remembers the page-locked
-    host buffer the strings were cut from.  ``decompress`` uploads that buffer directly instead of
-    re-joining thousands of small byte objects (the strings themselves are ordinary ``bytes``)."""
+    host buffers (one per pipeline chunk) the strings were cut from.  ``decompress`` uploads those
+    buffers directly instead of re-joining thousands of small byte objects (the strings themselves are
+    ordinary ``bytes``)."""
 
-    def __init__(self, strings, packed_host, byte_off):
+    def __init__(self, strings, segments):
         super().__init__(strings)
-        self.packed_host = packed_host  # pinned uint8 tensor
-        self.byte_off = byte_off        # np.int64 [B+1]
+        self.segments = segments  # [(first tile, tile count, pinned uint8 tensor, np.int64 offsets [n+1])]
 
     def still_packed(self):
-        if len(self) + 1 != self.byte_off.size:
+        if sum(n for _, n, _, _ in self.segments) != len(self):
             return False
         # cheap integrity check: lengths must still match the offsets (a caller may have edited the list)
-        n = len(self)
-        for i in (0, n // 2, n - 1):
-            if n and len(self[i]) != int(self.byte_off[i + 1] - self.byte_off[i]):
-                return False
+        for (s0, n, _, off) in self.segments:
+            for i in (0, n // 2, n - 1):
+                if len(self[s0 + i]) != int(off[i + 1] - off[i]):
+                    return False
         return True
 
 
@@ -76,14 +77,14 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
     B = x.shape[0]
     dev = x.device
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev)
+    side = _stream(dev, "coder")
+    copy = _stream(dev, "copy")
     med = eb.medians_vec()
     sec = _Section()
     sec.mark("c.start")
     sym = None
-    keep = []  # every tensor the side stream touches stays referenced until the final sync
     shape = None
-    per_chunk = []
+    queued = []  # every tensor another stream touches stays referenced here until its chunk is drained
     for (s0, n) in _chunks(B, chunk):
         y = net.g_a(x[s0:s0 + n])  # MFMA chain, main stream
         if sym is None:
@@ -99,42 +100,42 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
             side.wait_event(ready)
             words, nwords, status = ops.rans_encode_batch(sym, 1, B, nsym, plane, cdf, cdf_len, offset, table, cap_words,
                                                           n, sym_offset=s0)
-        keep.append((y, words, nwords, status))
-        per_chunk.append((s0, n, words, nwords, status))
-    done = torch.cuda.Event()
-    done.record(side)
-    main.wait_event(done)
-    sec.mark("c.transforms+encode (device)")
-    meta = torch.cat([t for (_, _, _, nw, st) in per_chunk for t in (nw, st)]).cpu().numpy()  # one D2H + sync
-    counts = np.empty(B, dtype=np.int64)
-    pos = 0
+            coded = torch.cuda.Event()
+            coded.record(side)
+        queued.append((s0, n, y, words, nwords, status, coded))
+    sec.mark("c.queue transforms+encode")
+    # drain chunk by chunk on the copy stream while later chunks are still in flight
+    strings = [None] * B
+    segments = []
     overflow = False
-    for (s0, n, _, _, _) in per_chunk:
-        counts[s0:s0 + n] = meta[pos:pos + n]
-        overflow |= bool(meta[pos + n])
-        pos += n + 1
+    for (s0, n, y, words, nwords, status, coded) in queued:
+        with torch.cuda.stream(copy):
+            copy.wait_event(coded)
+            meta = torch.cat((nwords, status)).cpu().numpy()  # synchronises the copy stream only
+            if meta[n]:
+                overflow = True
+                break
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(meta[:n].astype(np.int64) * 4, out=off[1:])
+            total = int(off[-1])
+            packed = torch.empty(max(total, 4), device=dev, dtype=torch.uint8)
+            ops.rans_compact(words, nwords, torch.from_numpy(off).to(dev), 0, out=packed)
+            host_t = torch.empty(max(total, 4), dtype=torch.uint8, pin_memory=True)
+            host_t.copy_(packed, non_blocking=True)
+            copy.synchronize()
+        mv = memoryview(host_t.numpy())
+        strings[s0:s0 + n] = [bytes(mv[off[i]:off[i + 1]]) for i in range(n)]
+        segments.append((s0, n, host_t, off))
     if overflow:
+        torch.cuda.synchronize(dev)
         if cap_words >= 2 * nsym + 8:
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
-        del keep, per_chunk
+        del queued
         return compress_fp16(net, x, chunk=chunk, cap_words=2 * nsym + 8)
-    sec.mark("c.lengths D2H")
-    byte_off = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum(counts * 4, out=byte_off[1:])
-    off_dev = torch.from_numpy(byte_off).to(dev)
-    packed = torch.empty(max(int(byte_off[-1]), 4), device=dev, dtype=torch.uint8)
-    for (s0, n, words, nwords, _) in per_chunk:
-        ops.rans_compact(words, nwords, off_dev, 0, out=packed, off_offset=s0)
-    sec.mark("c.compact")
-    host_t = torch.empty(packed.numel(), dtype=torch.uint8, pin_memory=True)
-    host_t.copy_(packed, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()
-    host = host_t.numpy()
-    sec.mark("c.bytes D2H")
-    mv = memoryview(host)
-    strings = PackedStrings([bytes(mv[byte_off[i]:byte_off[i + 1]]) for i in range(B)], host_t, byte_off)
-    sec.mark("c.python bytes objects")
-    return {"strings": [strings], "shape": torch.Size(shape)}
+    main.wait_stream(side)
+    main.wait_stream(copy)
+    sec.mark("c.drain (lengths, compact, D2H, bytes)")
+    return {"strings": [PackedStrings(strings, segments)], "shape": torch.Size(shape)}
 
 
 def decompress_fp16(net, strings, shape, chunk=1024):
@@ -147,36 +148,42 @@ def decompress_fp16(net, strings, shape, chunk=1024):
     C = cdf.shape[0]
     h, w = int(shape[0]), int(shape[1])
     nsym, plane = C * h * w, h * w
+    main = torch.cuda.current_stream(dev)
+    side = _stream(dev, "coder")
+    med = eb.medians_vec()
     sec = _Section()
     sec.mark("d.start")
-    if isinstance(strs, PackedStrings) and strs.still_packed():
-        total = int(strs.byte_off[-1])
-        data = strs.packed_host[:total].to(dev, non_blocking=True)
-        byte_off = torch.from_numpy(strs.byte_off).to(dev, non_blocking=True)
-    else:
-        data, byte_off = eb.pack_strings(strs, dev)
-    sec.mark("d.join + H2D")
-    main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev)
-    med = eb.medians_vec()
     sym = torch.empty((nsym, B), device=dev, dtype=torch.int32)
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     st = engine.stages(net.g_s)
     cout = st[-1][0].out_channels
     up = 2 ** len(st)
     x_hat = torch.empty((B, cout, h * up, w * up), device=dev, dtype=torch.float32)
+    # chunk list with each chunk's packed bytes: straight from compress()'s page-locked segments, or re-packed
+    if isinstance(strs, PackedStrings) and strs.still_packed():
+        pieces = [(s0, n, host_t, off) for (s0, n, host_t, off) in strs.segments]
+    else:
+        pieces = [(s0, n, None, None) for (s0, n) in _chunks(B, chunk)]
     start = torch.cuda.Event()
     start.record(main)
     side.wait_event(start)
     events = []
-    for (s0, n) in _chunks(B, chunk):
+    keep = []
+    for (s0, n, host_t, off) in pieces:
         with torch.cuda.stream(side):
+            if host_t is not None:
+                data = host_t[: max(int(off[-1]), 4)].to(dev, non_blocking=True)
+                byte_off = torch.from_numpy(off).to(dev, non_blocking=True)
+            else:
+                data, byte_off = eb.pack_strings(strs[s0:s0 + n], dev)
             ops.rans_decode_batch(data, byte_off, 1, B, nsym, plane, cdf, cdf_len, offset, sym, n, sym_offset=s0,
-                                  status=status)
+                                  status=status, off_offset=0)
             ev = torch.cuda.Event()
             ev.record(side)
+        keep.append((data, byte_off))
         events.append(ev)
-    for (s0, n), ev in zip(_chunks(B, chunk), events):
+    sec.mark("d.queue H2D+decode")
+    for (s0, n, _, _), ev in zip(pieces, events):
         main.wait_event(ev)
         y_blk = torch.zeros((n, (C + 15) // 16, h, w, 16), device=dev, dtype=torch.float16) if C % 16 else \
             torch.empty((n, C // 16, h, w, 16), device=dev, dtype=torch.float16)

@@ -254,12 +254,14 @@ def rans_compact(words, nwords, byte_off, total_bytes, out=None, off_offset=0):
 
 
 def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_len, offset, symbols, batch,
-                      indexes=None, sym_offset=0, status=None):
+                      indexes=None, sym_offset=0, status=None, off_offset=None):
     _dev(data, byte_off, cdf, cdf_len, offset, symbols, indexes)
     if status is None:
         status = torch.zeros(1, device=data.device, dtype=torch.int32)
     ip = _p(indexes) if indexes is None else _p_off(indexes, sym_offset)
-    rc = _lib.load().licos_rans_decode_batch(_p(data), _p_off(byte_off, sym_offset), ip, sym_stride_b, sym_stride_i, n, plane,
+    if off_offset is None:
+        off_offset = sym_offset
+    rc = _lib.load().licos_rans_decode_batch(_p(data), _p_off(byte_off, off_offset), ip, sym_stride_b, sym_stride_i, n, plane,
                                              _p(cdf), cdf.shape[1], _p(cdf_len), _p(offset), _p_off(symbols, sym_offset), _p(status),
                                              batch, _stream())
     _lib.check(rc, "rans_decode_batch")

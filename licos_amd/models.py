@@ -140,6 +140,8 @@ class FactorizedPrior(CompressionModel):
 
     def compress(self, x):
         self._sync_precision()
+        if x.shape[0] == 0:  # empty batch: nothing to launch
+            return {"strings": [[]], "shape": torch.Size((x.shape[2] // 16, x.shape[3] // 16))}
         if self.precision == "fp16":
             from .codec import compress_fp16
             return compress_fp16(self, x, chunk=self.chunk)
@@ -150,6 +152,10 @@ class FactorizedPrior(CompressionModel):
     def decompress(self, strings, shape):
         assert isinstance(strings, list) and len(strings) == 1
         self._sync_precision()
+        if len(strings[0]) == 0:
+            dev = self.entropy_bottleneck.quantiles.device
+            cout = self.g_s[len(self.g_s) - 1].out_channels
+            return {"x_hat": torch.zeros((0, cout, int(shape[0]) * 16, int(shape[1]) * 16), device=dev)}
         if self.precision == "fp16":
             from .codec import decompress_fp16
             return decompress_fp16(self, strings, shape, chunk=self.chunk)

@@ -330,3 +330,21 @@ def test_flat_state_average_single_gpu():
         y2 = net.g_a(x)
     assert rel_err(y2, y0) < 1e-5
     assert abs(float(fs.flat[-1]) - 0.37) < 1e-6
+
+
+def test_edge_batches_and_sizes():
+    """Empty batch, a single tile, a batch that does not fill a wave, and the smallest legal tile (16x16)."""
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=2)
+    for precision in ("fp32", "fp16"):
+        net = _load(3, sd, precision=precision)
+        with torch.no_grad():
+            empty = net.compress(torch.zeros(0, 3, 64, 64, device=DEV))
+            assert list(empty["strings"][0]) == [] and tuple(empty["shape"]) == (4, 4)
+            assert tuple(net.decompress(empty["strings"], empty["shape"])["x_hat"].shape) == (0, 3, 64, 64)
+            for b, size in ((1, 16), (1, 64), (3, 32), (65, 16)):
+                x = om.synthetic_tiles(b, 3, 64, seed=b)[:, :, :size, :size].contiguous().to(DEV)
+                comp = net.compress(x)
+                assert len(comp["strings"][0]) == b and tuple(comp["shape"]) == (size // 16, size // 16)
+                dec = net.decompress(comp["strings"], comp["shape"])
+                out = net(x)
+                assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-5

@@ -128,6 +128,16 @@ int licos_gc_likelihood(const float *v, const float *scales, float *lik, float s
 int licos_gc_build_indexes(const float *scales, const float *table, int levels, float scale_bound, int32_t *indexes,
                            long stride_b, long stride_i, int B, long n, void *stream);
 
+/* Sentinel-2 raw DN -> model input grid (the step before the path):
+ * /root/reference/licos/raw_image_folder.py:192-196 with use_full_range=False: x = DN / 4095 (raw_utils.py:128),
+ * then skimage.img_as_ubyte(x) / 255 = rint(x * 255) / 255.  dn: uint16 [n]; out: fp32 [n]. */
+int licos_dn12_to_grid8_f32(const uint16_t *dn, float *out, long n, int full_range, void *stream);
+/* Cuts (B, C, H, W) images into T x T tiles (zero padded at the right/bottom edge) laid out as a tile batch
+ * (B*ny*nx, C, T, T), and the inverse (crop back).  Whole granules (raw_utils.py:131: up to 2304 x 2592) then
+ * ride the batched tile codec instead of one 4.5-M-symbol stream. */
+int licos_tile_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, void *stream);
+int licos_untile_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, void *stream);
+
 /* mean-squared-error numerator: sum over all elements of (a-b)^2 into *out (double, zeroed by caller);
  * /root/reference/eval_utils.py:145-156, RateDistortionLoss mse term.  clamp01 != 0 clamps `a` first. */
 int licos_reduce_sqdiff(const float *a, const float *b, long n, int clamp01, double *out, void *stream);

@@ -34,6 +34,9 @@ SIGNATURES = {
     "licos_rans_decode_batch": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "licos_gc_likelihood": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
     "licos_gc_build_indexes": (_i, [_vp, _vp, _i, _f, _vp, _l, _l, _i, _l, _vp]),
+    "licos_dn12_to_grid8_f32": (_i, [_vp, _vp, _l, _i, _vp]),
+    "licos_tile_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_untile_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_scale_f32": (_i, [_vp, _l, _f, _vp, _vp]),
     "licos_packed_conv_w_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_conv_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -316,6 +316,32 @@ __global__ void gc_build_indexes_kernel(const float *__restrict__ scales, const 
   }
 }
 
+// ---- granule pre/post-processing ---------------------------------------------------------
+__global__ void dn12_to_grid8_kernel(const uint16_t *__restrict__ dn, float *__restrict__ out, long n, int full_range) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const double v = (double)dn[e] / 4095.0;
+    out[e] = full_range ? (float)v : (float)(rint(v * 255.0) / 255.0);
+  }
+}
+
+// dir 0: image -> tiles, 1: tiles -> image.  One thread per tile element; x fastest (coalesced both sides).
+__global__ void tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int H, int W, int T, int ny,
+                            int nx, long total, int dir) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tx = (int)(e % T);
+    const int ty = (int)((e / T) % T);
+    const int c = (int)((e / ((long)T * T)) % C);
+    const long t = e / ((long)T * T * C);
+    const int ix = (int)(t % nx), iy = (int)((t / nx) % ny);
+    const long b = t / ((long)nx * ny);
+    const int y = iy * T + ty, x = ix * T + tx;
+    const bool in = y < H && x < W;
+    const size_t img = (((size_t)b * C + c) * H + y) * W + x;
+    if (dir == 0) dst[e] = in ? src[img] : 0.f;
+    else if (in) dst[img] = src[e];
+  }
+}
+
 __global__ void scale_f32_kernel(float *__restrict__ x, long n, float alpha, const float *__restrict__ inv_alpha) {
   const float a = inv_alpha ? alpha / inv_alpha[0] : alpha;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) x[e] *= a;
@@ -443,6 +469,32 @@ int licos_gc_build_indexes(const float *scales, const float *table, int levels, 
                      scale_bound, indexes, stride_b, stride_i, n, total);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
+}
+
+int licos_dn12_to_grid8_f32(const uint16_t *dn, float *out, long n, int full_range, void *stream) {
+  LICOS_REQUIRE(dn && out && n > 0, "dn12_to_grid8_f32: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dn12_to_grid8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dn, out, n, full_range);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+static int tile_launch(const float *src, float *dst, int B, int C, int H, int W, int T, int dir, void *stream) {
+  LICOS_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && T > 0, "tile: bad arguments");
+  const int ny = cdiv(H, T), nx = cdiv(W, T);
+  const long total = (long)B * ny * nx * C * T * T;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(tile_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, C, H, W, T, ny, nx, total, dir);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_tile_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, void *stream) {
+  return tile_launch(img, tiles, B, C, H, W, T, 0, stream);
+}
+
+int licos_untile_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, void *stream) {
+  return tile_launch(tiles, img, B, C, H, W, T, 1, stream);
 }
 
 int licos_scale_f32(float *x, long n, float alpha, const float *inv_alpha_dev, void *stream) {

@@ -348,3 +348,25 @@ def test_edge_batches_and_sizes():
                 dec = net.decompress(comp["strings"], comp["shape"])
                 out = net(x)
                 assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-5
+
+
+def test_granule_tiling_and_dn_conversion():
+    """DN -> 8-bit grid as raw_image_folder.py:192-196, tiling of a non-multiple-of-256 image."""
+    from licos_amd import tiling
+    g = torch.Generator().manual_seed(0)
+    dn = torch.randint(0, 4096, (1, 1, 300, 520), generator=g, dtype=torch.int32).to(torch.uint16)
+    x = tiling.dn12_to_grid8(dn.to(DEV))
+    ref = np.rint(dn.numpy().astype(np.float64) / 4095.0 * 255.0) / 255.0
+    assert np.array_equal(x.cpu().numpy(), ref.astype(np.float32))
+    full = tiling.dn12_to_grid8(dn.to(DEV), full_range=True)
+    assert np.array_equal(full.cpu().numpy(), (dn.numpy().astype(np.float64) / 4095.0).astype(np.float32))
+    tiles, geo = tiling.tile(x, 256)
+    assert tuple(tiles.shape) == (2 * 3, 1, 256, 256)
+    assert torch.equal(tiles[0, 0], x[0, 0, :256, :256]) and float(tiles[5, 0, 44:, :].abs().max()) == 0.0
+    assert torch.equal(tiling.untile(tiles, geo), x)
+    sd = om.perturb_state(om.make_factorized_state(1, 1), seed=2)
+    net = _load(1, sd, precision="fp16")
+    with torch.no_grad():
+        coded = tiling.compress_image(net, x)
+        rec = tiling.decompress_image(net, coded)["x_hat"]
+    assert len(coded["strings"][0]) == 6 and tuple(rec.shape) == tuple(x.shape)

@@ -28,6 +28,20 @@ def stage_flops(kind, cin, cout, h, w):
     return 2.0 * pix_out * taps * cin * cout
 
 
+def quality_match(net, sd, x8):
+    """bpp / PSNR of the GPU fp16 path vs the CPU oracle on the same 8 tiles (the "matched" of the metric)."""
+    import torch
+    import licos_amd
+    from oracle import model as om
+    with torch.no_grad():
+        out = net(x8)
+    ref = om.forward(x8.cpu(), sd)
+    return {"tiles": int(x8.shape[0]),
+            "bpp_gpu": round(licos_amd.metrics.compute_bpp(out), 5), "bpp_oracle": round(om.compute_bpp(ref), 5),
+            "psnr_gpu": round(licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x8), 4),
+            "psnr_oracle": round(om.compute_psnr(ref["x_hat"].clamp(0, 1), x8.cpu()), 4)}
+
+
 def cpu_baseline(sd, cin, batch, reps):
     """The oracle (torch-CPU conv = the reference's CPU arithmetic; restated EB; C rANS) timed on
     this host's cores on a bounded sample of the same workload."""
@@ -65,6 +79,9 @@ def main():
     import licos_amd
     from licos_amd import _lib, engine, synthetic
 
+    if not os.path.exists(_lib.SO_PATH):  # a source-only checkout: compile the HIP library first (hipcc, ~1 min)
+        import __graft_entry__
+        __graft_entry__.build()
     _lib.load()  # the HIP library is the product: fail loudly if it is missing
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -172,7 +189,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         tps, dt, threads = cpu_baseline(sd, args.channels, 32, 8)
-        cpu = {"value": round(tps, 2), "unit": "tiles/s", "cores": threads, "kind": "port",
+        match = quality_match(net, sd, x[:8])
+        cpu = {"value": round(tps, 2), "unit": "tiles/s", "cores": threads, "kind": "port", "quality_match": match,
                "sample": "oracle compress+decompress (torch-CPU conv, C rANS), 8 reps x 32 tiles of the same 3x256x256 "
                          "workload, %.1f s, %d torch threads on a %d-core host" % (dt, threads, os.cpu_count() or 0)}
 

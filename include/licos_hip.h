@@ -85,6 +85,24 @@ int licos_gdn_reparam_f32(const float *beta_raw, const float *gamma_raw, float b
 int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C,
                   int HW, int inverse, void *stream);
 
+/* ------------------------------------------------ backward, 32-bit path
+ * What licos/train.py:193 (`loss.backward()`) computes through torch autograd for the transforms.
+ * Input gradients need no entry point of their own: dgrad(Conv2d) = licos_deconv2d_f32 and
+ * dgrad(ConvTranspose2d) = licos_conv2d_f32 on the same weight tensor.
+ *
+ * Weight gradient of a K x K, stride-S cross-correlation: dw[co][ci][ky][kx] = sum_{b,oy,ox} g[b][co][oy][ox] *
+ * inp[b][ci][oy*S-pad+ky][ox*S-pad+kx] (inp squared first when square_input != 0: the GDN gamma gradient as a 1x1 case).
+ * Conv2d: inp = x, g = dy.  ConvTranspose2d: inp = dy, g = x (dw then has the [Cin][Cout][K][K] layout). dw is overwritten. */
+int licos_conv2d_wgrad_f32(const float *inp /*[B][Ci][H][W]*/, const float *g /*[B][Co][Ho][Wo]*/, float *dw, int B,
+                           int Ci, int H, int W, int Co, int K, int stride, int pad, int square_input, void *stream);
+int licos_bias_grad_f32(const float *dy /*[B][C][HW]*/, float *db /*[C]*/, int B, int C, long HW, void *stream);
+/* GDN backward: dx, and t = dL/dnorm (dgamma_eff = licos_conv2d_wgrad_f32(x, t, K=1, square_input=1), dbeta_eff =
+ * licos_bias_grad_f32(t)); gamma_t_scratch: C*C floats. */
+int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, const float *beta_eff,
+                      float *gamma_t_scratch, float *dx, float *t_out, int B, int C, int HW, int inverse, void *stream);
+/* NonNegativeParametrizer backward incl. CompressAI's LowerBound gradient rule. */
+int licos_reparam_bwd_f32(const float *raw, const float *d_eff, float bound, float *d_raw, long n, void *stream);
+
 /* ------------------------------------------- entropy bottleneck (fp32 math)
  * CompressAI entropy_models/entropy_models.py EntropyBottleneck, constructed at
  * licos/model_utils.py:25-29.

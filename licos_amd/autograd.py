@@ -56,6 +56,93 @@ class HipForward(torch.autograd.Function):
         return (None, None, *res)
 
 
+class ConvHip(torch.autograd.Function):
+    """Conv2d with HIP forward AND backward (dgrad = transposed-conv kernel, wgrad / bias-grad kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        from . import ops
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, b is not None)
+        return ops.conv2d_f32(x, w.detach(), None if b is None else b.detach(), stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        k = w.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            out_pad = x.shape[2] - ((dy.shape[2] - 1) * stride - 2 * pad + k)
+            dx = ops.deconv2d_f32(dy, w.detach(), None, stride, pad, out_pad)
+            if dx.shape != x.shape:  # width and height may need different output paddings
+                dx = torch.nn.functional.pad(dx, (0, x.shape[3] - dx.shape[3], 0, 0))
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad_f32(x, dy, w.shape[1], w.shape[0], k, stride, pad)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.bias_grad_f32(dy)
+        return dx, dw, db, None, None
+
+
+class DeconvHip(torch.autograd.Function):
+    """ConvTranspose2d with HIP forward and backward (dgrad = conv kernel on the same weights)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad):
+        from . import ops
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, b is not None)
+        return ops.deconv2d_f32(x, w.detach(), None if b is None else b.detach(), stride, pad, out_pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        k = w.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_f32(dy, w.detach(), None, stride, pad)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad_f32(dy, x, w.shape[1], w.shape[0], k, stride, pad)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.bias_grad_f32(dy)
+        return dx, dw, db, None, None, None
+
+
+class GdnHip(torch.autograd.Function):
+    """GDN / IGDN with HIP forward and backward, incl. the reparametrisation chain."""
+
+    @staticmethod
+    def forward(ctx, x, beta_raw, gamma_raw, inverse, beta_bound, gamma_bound, pedestal):
+        from . import ops
+        x = x.contiguous()
+        beta, gamma = ops.gdn_reparam_f32(beta_raw.detach(), gamma_raw.detach(), beta_bound, gamma_bound, pedestal)
+        ctx.save_for_backward(x, beta_raw, gamma_raw, beta, gamma)
+        ctx.cfg = (inverse, beta_bound, gamma_bound)
+        return ops.gdn_f32(x, gamma, beta, inverse)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, beta_raw, gamma_raw, beta, gamma = ctx.saved_tensors
+        inverse, beta_bound, gamma_bound = ctx.cfg
+        c = x.shape[1]
+        dx, t = ops.gdn_bwd_f32(x, dy.contiguous(), gamma, beta, inverse)
+        dbeta = dgamma = None
+        if ctx.needs_input_grad[1]:
+            dbeta = ops.reparam_bwd_f32(beta_raw.detach(), ops.bias_grad_f32(t), beta_bound)
+        if ctx.needs_input_grad[2]:
+            dg_eff = ops.conv2d_wgrad_f32(x, t, c, c, 1, 1, 0, square_input=True).reshape(c, c)
+            dgamma = ops.reparam_bwd_f32(gamma_raw.detach(), dg_eff, gamma_bound)
+        return (dx if ctx.needs_input_grad[0] else None), dbeta, dgamma, None, None, None, None
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 

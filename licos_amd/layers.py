@@ -79,12 +79,7 @@ class GDN(nn.Module):
         from . import autograd
         if autograd.needs_grad(x, self.beta, self.gamma):
             bb, gb, ped = self.reparam_args()
-
-            def hip(xx, beta_raw, gamma_raw):
-                beta, gamma = ops.gdn_reparam_f32(beta_raw, gamma_raw, bb, gb, ped)
-                return ops.gdn_f32(xx.contiguous(), gamma, beta, self.inverse)
-
-            return autograd.HipForward.apply(hip, autograd.gdn_ref(self.inverse, bb, gb, ped), x, self.beta, self.gamma)
+            return autograd.GdnHip.apply(x, self.beta, self.gamma, self.inverse, bb, gb, ped)  # HIP forward and backward
         beta, gamma = self.effective()
         return ops.gdn_f32(x.contiguous(), gamma, beta, self.inverse)
 

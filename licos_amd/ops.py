@@ -121,6 +121,46 @@ def gdn_f32(x, gamma_eff, beta_eff, inverse=False):
     return y
 
 
+# ----------------------------------------------------------------------------- backward (32-bit path)
+def conv2d_wgrad_f32(inp, g, ci, co, k, stride, pad, square_input=False):
+    """dw [co][ci][k][k] = sum g[b][co][oy][ox] * inp[b][ci][oy*s-p+ky][ox*s-p+kx]."""
+    _dev(inp, g)
+    b, _, h, w = inp.shape
+    dw = torch.empty((co, ci, k, k), device=inp.device, dtype=torch.float32)
+    rc = _lib.load().licos_conv2d_wgrad_f32(_p(_f32(inp)), _p(_f32(g)), _p(dw), b, ci, h, w, co, k, stride, pad,
+                                            int(square_input), _stream())
+    _lib.check(rc, "conv2d_wgrad_f32")
+    return dw
+
+
+def bias_grad_f32(dy):
+    _dev(dy)
+    b, c = dy.shape[:2]
+    db = torch.empty(c, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().licos_bias_grad_f32(_p(_f32(dy)), _p(db), b, c, dy[0, 0].numel(), _stream()), "bias_grad_f32")
+    return db
+
+
+def gdn_bwd_f32(x, dy, gamma_eff, beta_eff, inverse):
+    _dev(x, dy, gamma_eff, beta_eff)
+    b, c = x.shape[:2]
+    hw = x[0, 0].numel()
+    dx, t = torch.empty_like(x), torch.empty_like(x)
+    scratch = torch.empty_like(gamma_eff)
+    rc = _lib.load().licos_gdn_bwd_f32(_p(_f32(x)), _p(_f32(dy)), _p(gamma_eff), _p(beta_eff), _p(scratch), _p(dx), _p(t),
+                                       b, c, hw, int(inverse), _stream())
+    _lib.check(rc, "gdn_bwd_f32")
+    return dx, t
+
+
+def reparam_bwd_f32(raw, d_eff, bound):
+    _dev(raw, d_eff)
+    out = torch.empty_like(raw)
+    rc = _lib.load().licos_reparam_bwd_f32(_p(_f32(raw)), _p(_f32(d_eff.contiguous())), bound, _p(out), raw.numel(), _stream())
+    _lib.check(rc, "reparam_bwd_f32")
+    return out
+
+
 # ----------------------------------------------------------------------------- entropy bottleneck
 def _filters_arr(filters):
     return (ctypes.c_int * len(filters))(*[int(f) for f in filters])

@@ -59,3 +59,64 @@ def test_train_step_matches_cpu_autograd():
         net(x.to(DEV))
     with torch.no_grad():
         net.eval()(x.to(DEV))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k,s", [(3, 16, 20, 28, 5, 2), (16, 24, 17, 33, 5, 2), (8, 8, 9, 9, 3, 1),
+                                               (32, 64, 16, 16, 5, 2), (130, 70, 8, 8, 5, 2)])
+def test_conv_backward_kernels(cin, cout, h, w, k, s):
+    """dgrad (transposed-conv kernel), wgrad and bias-grad kernels against torch CPU autograd."""
+    from licos_amd import autograd
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(3, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    ref = torch.nn.functional.conv2d(x, wt, b, stride=s, padding=k // 2)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, wt, b))
+    out = autograd.ConvHip.apply(xd, wd, bd, s, k // 2)
+    out.backward(go.to(DEV))
+    for got, want in ((xd.grad, x.grad), (wd.grad, wt.grad), (bd.grad, b.grad)):
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 3, 10, 14), (24, 16, 9, 17), (192, 40, 4, 4)])
+def test_deconv_backward_kernels(cin, cout, h, w):
+    from licos_amd import autograd
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cin, cout, 5, 5, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, wt, b))
+    out = autograd.DeconvHip.apply(xd, wd, bd, 2, 2, 1)
+    out.backward(go.to(DEV))
+    for got, want in ((xd.grad, x.grad), (wd.grad, wt.grad), (bd.grad, b.grad)):
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_backward_kernel(inverse):
+    c = 128
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    om._gdn_init(sd, "g.", c)
+    sd["g.gamma"] = (sd["g.gamma"] + 0.05 * torch.rand(c, c, generator=g))
+    sd["g.beta"] = sd["g.beta"] * (0.5 + torch.rand(c, generator=g))
+    x = (2 * torch.randn(2, c, 9, 11, generator=g)).requires_grad_(True)
+    ref_sd = dict(sd)
+    ref_sd["g.gamma"] = sd["g.gamma"].clone().requires_grad_(True)
+    ref_sd["g.beta"] = sd["g.beta"].clone().requires_grad_(True)
+    ref = om.gdn(x, ref_sd, "g.", inverse=inverse)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    m = licos_amd.GDN(c, inverse=inverse)
+    m.load_state_dict({k[2:]: v for k, v in sd.items()})
+    m = m.to(DEV)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    out = m(xd)
+    out.backward(go.to(DEV))
+    for got, want in ((xd.grad, x.grad), (m.gamma.grad, ref_sd["g.gamma"].grad), (m.beta.grad, ref_sd["g.beta"].grad)):
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) < 5e-5

@@ -103,6 +103,14 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
 /* NonNegativeParametrizer backward incl. CompressAI's LowerBound gradient rule. */
 int licos_reparam_bwd_f32(const float *raw, const float *d_eff, float bound, float *d_raw, long n, void *stream);
 
+/* torch.optim.Adam.step (licos/train.py:196,200; defaults amsgrad=False, weight_decay=0) on one flat fp32 tensor:
+ * m = b1 m + (1-b1) g', v = b2 v + (1-b2) g'^2, p -= lr / (1-b1^t) * m / (sqrt(v / (1-b2^t)) + eps), g' = g * grad_scale
+ * (grad_scale carries clip_grad_norm_'s coefficient, train.py:194-195). */
+int licos_adam_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, float grad_scale, void *stream);
+/* sum of squares into *out (double, zeroed by the caller): the total-norm reduction of clip_grad_norm_. */
+int licos_sumsq_f32(const float *x, long n, double *out, void *stream);
+
 /* ------------------------------------------- entropy bottleneck (fp32 math)
  * CompressAI entropy_models/entropy_models.py EntropyBottleneck, constructed at
  * licos/model_utils.py:25-29.

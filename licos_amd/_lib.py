@@ -27,6 +27,8 @@ SIGNATURES = {
     "licos_bias_grad_f32": (_i, [_vp, _vp, _i, _i, _l, _vp]),
     "licos_gdn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_reparam_bwd_f32": (_i, [_vp, _vp, _f, _vp, _l, _vp]),
+    "licos_adam_f32": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f, _vp]),
+    "licos_sumsq_f32": (_i, [_vp, _l, _vp, _vp]),
     "licos_eb_packed_size": (_i, [_vp, _i]),
     "licos_eb_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "licos_eb_quantize": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp]),

@@ -5,6 +5,8 @@
 // licos/train.py:193 (`out_criterion["loss"].backward()`) is where the reference runs this arithmetic
 // through torch autograd; the maths restated here is the standard adjoint of the forward definitions in
 // conv_f32.hip (cross-correlation) and of CompressAI layers/gdn.py.
+#include <cmath>
+
 #include "common.hpp"
 
 namespace licos {
@@ -165,6 +167,29 @@ __global__ void transpose_sq_f32_kernel(const float *__restrict__ a, float *__re
   if (i < C * C) at[(size_t)(i % C) * C + i / C] = a[i];
 }
 
+__global__ void adam_f32_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                float *__restrict__ v, long n, float lr_t, float beta1, float beta2, float eps,
+                                float inv_sqrt_bc2, float grad_scale) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float gr = g[e] * grad_scale;
+    const float mm = beta1 * m[e] + (1.f - beta1) * gr;
+    const float vv = beta2 * v[e] + (1.f - beta2) * gr * gr;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] -= lr_t * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_f32_kernel(const float *__restrict__ x, long n, double *__restrict__ out) {
+  __shared__ double s_red[4];
+  double local = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) local += (double)x[e] * x[e];
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
 }  // namespace licos
 
 using namespace licos;
@@ -223,6 +248,25 @@ int licos_reparam_bwd_f32(const float *raw, const float *d_eff, float bound, flo
   LICOS_REQUIRE(raw && d_eff && d_raw && n > 0, "reparam_bwd_f32: bad arguments");
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(reparam_bwd_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), raw, d_eff, bound, d_raw, n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_adam_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, float grad_scale, void *stream) {
+  LICOS_REQUIRE(p && g && m && v && n > 0 && step > 0, "adam_f32: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(adam_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, (float)(lr / bc1), beta1,
+                     beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_sumsq_f32(const float *x, long n, double *out, void *stream) {
+  LICOS_REQUIRE(x && out && n > 0, "sumsq_f32: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(sumsq_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, out);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

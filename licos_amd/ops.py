@@ -161,6 +161,18 @@ def reparam_bwd_f32(raw, d_eff, bound):
     return out
 
 
+def adam_f32(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _dev(p, g, m, v)
+    rc = _lib.load().licos_adam_f32(_p(_f32(p)), _p(_f32(g)), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step,
+                                    grad_scale, _stream())
+    _lib.check(rc, "adam_f32")
+
+
+def sumsq_f32(x, out):
+    _dev(x, out)
+    _lib.check(_lib.load().licos_sumsq_f32(_p(_f32(x)), x.numel(), _p(out), _stream()), "sumsq_f32")
+
+
 # ----------------------------------------------------------------------------- entropy bottleneck
 def _filters_arr(filters):
     return (ctypes.c_int * len(filters))(*[int(f) for f in filters])

@@ -120,3 +120,31 @@ def test_gdn_backward_kernel(inverse):
     out.backward(go.to(DEV))
     for got, want in ((xd.grad, x.grad), (m.gamma.grad, ref_sd["g.gamma"].grad), (m.beta.grad, ref_sd["g.beta"].grad)):
         assert float((got.cpu() - want).abs().max() / want.abs().max()) < 5e-5
+
+
+def test_fused_adam_and_clip_match_torch():
+    from licos_amd import optimizers
+    g = torch.Generator().manual_seed(1)
+    ps = [torch.randn(1000, generator=g), torch.randn(7, 13, generator=g)]
+    grads = [[torch.randn(p.shape, generator=g) * (3.0 if it == 0 else 0.01) for p in ps] for it in range(3)]
+    ref_p = [p.clone().requires_grad_(True) for p in ps]
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-2)
+    dev_p = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    opt = optimizers.FusedAdam(dev_p, lr=1e-2)
+    for it in range(3):
+        for p, q, gr in zip(ref_p, dev_p, grads[it]):
+            p.grad = gr.clone()
+            q.grad = gr.clone().to(DEV)
+        n_ref = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        n_dev = optimizers.clip_grad_norm_(dev_p, 1.0, optimizer=opt)
+        assert abs(float(n_ref) - float(n_dev)) < 1e-4 * float(n_ref)
+        ref_opt.step()
+        opt.step()
+        for p, q in zip(ref_p, dev_p):
+            assert torch.allclose(p.detach(), q.detach().cpu(), rtol=1e-5, atol=1e-7)
+    # without an optimizer the gradients themselves are rescaled, like torch's
+    for q, gr in zip(dev_p, grads[0]):
+        q.grad = gr.clone().to(DEV)
+    optimizers.clip_grad_norm_(dev_p, 1.0)
+    tot = sum(float((q.grad.double() ** 2).sum()) for q in dev_p) ** 0.5
+    assert abs(tot - 1.0) < 1e-3

@@ -23,6 +23,8 @@ PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16 MFMA (MI355X_MICROARCH.md
 
 def stage_flops(kind, cin, cout, h, w):
     """Algorithmic FLOPs of one stage per tile (conv + fused GDN MACs x 2), input size h x w."""
+    if kind == "conv3":
+        return 2.0 * h * w * 9 * cin * cout
     pix_out = (h // 2) * (w // 2) if kind == "conv" else (2 * h) * (2 * w)
     taps = 25 if kind == "conv" else 25 / 4.0
     return 2.0 * pix_out * taps * cin * cout
@@ -68,6 +70,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=4096, help="tiles per pipeline chunk inside a step")
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--quality", type=int, default=3)
+    ap.add_argument("--model", default="bmshj2018-factorized", help="zoo name (secondary configs: bmshj2018-hyperprior)")
+    ap.add_argument("--size", type=int, default=256, help="tile edge (BASELINE configs[4] uses 512)")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -99,13 +103,14 @@ def main():
             dist.init_process_group(args.backend)
 
     torch.manual_seed(42)
-    net = licos_amd.get_model("bmshj2018-factorized", False, args.channels, args.quality)
+    net = licos_amd.get_model(args.model, False, args.channels, args.quality)
     net = net.to(dev).eval().set_precision(args.precision)
     net.chunk = args.chunk
     with torch.no_grad():
         synthetic.make_trained_like(net, seed=0)
     B = args.batch
-    x = synthetic.tiles(B, args.channels, 256, seed=100 + rank, device=dev)
+    kind = "aid" if args.channels == 3 else ("s2-merged" if args.channels == 13 else "s2")
+    x = synthetic.tiles(B, args.channels, args.size, seed=100 + rank, kind=kind, device=dev)
 
     def step():
         with torch.no_grad():
@@ -135,8 +140,8 @@ def main():
         elapsed = float(t.item())
 
     # quality of what was just coded (bpp from the actual bytes; PSNR of the decoded tiles)
-    nbytes = sum(len(s) for s in comp["strings"][0])
-    bpp = nbytes * 8.0 / (B * 256 * 256)
+    nbytes = sum(len(s) for lst in comp["strings"] for s in lst)
+    bpp = nbytes * 8.0 / (B * args.size * args.size)
     psnr = licos_amd.metrics.compute_psnr(dec["x_hat"], x)
 
     stages = {}
@@ -186,7 +191,7 @@ def main():
                "what": "scale + RCCL all-reduce(SUM) + normalise of the whole floating state, per averaging step"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "bmshj2018-factorized" and args.size == 256:
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         tps, dt, threads = cpu_baseline(sd, args.channels, 32, 8)
         match = quality_match(net, sd, x[:8])
@@ -197,12 +202,14 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         line = {
-            "metric": "256x256 tiles/s encode+decode (bpp+PSNR matched)", "value": round(value, 1), "unit": "tiles/s",
+            "metric": "256x256 tiles/s encode+decode (bpp+PSNR matched)" if args.size == 256 else
+            "%dx%d tiles/s encode+decode" % (args.size, args.size), "value": round(value, 1), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": "bmshj2018_factorized q=%d, %d-ch 256x256 tiles, compress()+decompress() through the "
-                                   "module API, %d tiles per GPU per step" % (args.quality, args.channels, B),
+            "config": {"workload": "%s q=%d, %d-ch %dx%d tiles, compress()+decompress() through the "
+                                   "module API, %d tiles per GPU per step" % (args.model.replace("-", "_"), args.quality,
+                                                                              args.channels, args.size, args.size, B),
                        "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": "synthetic trained-like (seeded)"},
             "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
             "roofline": roof, "cpu_baseline": cpu, "fedavg_allreduce": fed, "stages": stages,

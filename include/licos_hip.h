@@ -224,8 +224,13 @@ int licos_pack_deconv_w_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int C
 size_t licos_packed_gdn_bytes(int C);
 int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
                         float pedestal, int C, void *packed, void *stream);
-/* NCHW fp32 -> blk16 fp16 (channels zero-padded to a multiple of 16) */
-int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
+/* NCHW fp32 -> blk16 fp16 (channels zero-padded to a multiple of 16); abs_input != 0 stores |x| (ScaleHyperprior h_a) */
+int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, int abs_input, void *stream);
+/* 3x3 stride-1 padding-1 Conv2d on the MFMA path (hyperprior h_a[0], h_s[4]): same kernel as one output phase of the
+ * transposed conv, weights packed by licos_pack_conv3x3_w_f16 ([Cout][Cin][3][3] in). */
+int licos_pack_conv3x3_w_f16(const float *w, int Cin, int Cout, void *packed, void *stream);
+int licos_conv3x3s1_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed, int epilogue,
+                        void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout, void *stream);
 int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream);
 
 /* First analysis stage for few input channels (Cin <= 4: RGB, single Sentinel-2 band): a 5x5 stride-2 conv over

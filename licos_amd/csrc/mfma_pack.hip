@@ -144,8 +144,25 @@ __global__ void nchw_to_s2d_blk16_kernel(const float *__restrict__ x, _Float16 *
   }
 }
 
+// 3x3 stride-1 conv weights [Cout][Cin][3][3] -> [cc][t = iky*3+ikx][mt][lane][8]; the kernel reads the input at
+// (dy, dx) = (1 - iky, 1 - ikx), i.e. tap (ky, kx) = (2 - iky, 2 - ikx)
+__global__ void pack_conv3x3_w_kernel(const float *__restrict__ w, int Cin, int Cout, int C16, int MT,
+                                      _Float16 *__restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int mt = (int)(rest % MT); rest /= MT;
+    const int t = (int)(rest % 9), cc = (int)(rest / 9);
+    const int co = 32 * mt + (lane & 31), ci = 16 * cc + 8 * (lane >> 5) + j;
+    const int ky = 2 - t / 3, kx = 2 - t % 3;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+    out[e] = (_Float16)v;
+  }
+}
+
 __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int C16, long HW,
-                                     long total) {
+                                     long total, int abs_input) {
   // one thread per (b, chunk, pixel): writes 16 halfs (32 B)
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long p = e % HW;
@@ -155,8 +172,11 @@ __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__re
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c0 = cc * 16 + j, c1 = c0 + 8;
-      lo[j] = (c0 < C) ? (_Float16)x[((size_t)b * C + c0) * HW + p] : (_Float16)0.f;
-      hi[j] = (c1 < C) ? (_Float16)x[((size_t)b * C + c1) * HW + p] : (_Float16)0.f;
+      float v0 = (c0 < C) ? x[((size_t)b * C + c0) * HW + p] : 0.f;
+      float v1 = (c1 < C) ? x[((size_t)b * C + c1) * HW + p] : 0.f;
+      if (abs_input) { v0 = fabsf(v0); v1 = fabsf(v1); }
+      lo[j] = (_Float16)v0;
+      hi[j] = (_Float16)v1;
     }
     half8 *dst = reinterpret_cast<half8 *>(y + (size_t)e * 16);
     dst[0] = lo;
@@ -265,12 +285,23 @@ int licos_pack_conv_w_s2d_f16(const float *w, int Cin, int Cout, void *packed, v
   return LICOS_OK;
 }
 
-int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
+int licos_pack_conv3x3_w_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
+  const int MT = mt_for(Cout);
+  LICOS_REQUIRE(w && packed && Cin > 0 && MT > 0, "pack_conv3x3_w_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  const int C16 = (Cin + 15) / 16;
+  const long total = (long)C16 * 9 * MT * 512;
+  hipLaunchKernelGGL(pack_conv3x3_w_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                     as_stream(stream), w, Cin, Cout, C16, MT, static_cast<_Float16 *>(packed), total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, int abs_input, void *stream) {
   LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_blk16: bad arguments");
   const int C16 = (C + 15) / 16;
   const long HW = (long)H * W, total = (long)B * C16 * HW;
   hipLaunchKernelGGL(nchw_to_blk16_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,
-                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), C, C16, HW, total);
+                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), C, C16, HW, total, abs_input);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
@@ -379,4 +410,17 @@ extern "C" int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_pa
   a.Wo = 2 * W;
   a.clamp01 = clamp01;
   return mfma_launch_deconv_fewch(a, as_stream(stream));
+}
+
+extern "C" int licos_conv3x3s1_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
+                                   int epilogue, void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout,
+                                   void *stream) {
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_blk16, w_packed, bias, gdn_packed, epilogue, y_blk16, y_nchw, B, Cin, H, W, Cout, &MT, "conv3x3s1_f16");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = H;
+  a.Wo = W;
+  a.s1conv = 1;
+  return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
 }

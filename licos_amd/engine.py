@@ -44,12 +44,15 @@ def _packed_conv(m, s2d=False, fewch=False):
     if ent is None or ent[0] != key:
         transposed = isinstance(m, nn.ConvTranspose2d)
         geo = conv_geometry(m)
-        if geo[:3] != (5, 2, 2) or (transposed and geo[3] != 1):
-            raise ValueError("licos_amd: the fp16 MFMA path implements kernel 5 / stride 2 / padding 2 "
-                             "(output_padding 1) stages only; use precision='fp32' for other shapes")
+        k3 = (not transposed) and geo[:3] == (3, 1, 1)
+        if not k3 and (geo[:3] != (5, 2, 2) or (transposed and geo[3] != 1)):
+            raise ValueError("licos_amd: the fp16 MFMA path implements 5x5 stride-2 (de)convolutions and 3x3 "
+                             "stride-1 convolutions; use precision='fp32' for other shapes")
         cout = m.out_channels
         if fewch:
             wp = ops.pack_deconv_w_fewch_f16(m.weight.detach())
+        elif k3:
+            wp = ops.pack_conv3x3_w_f16(m.weight.detach())
         elif s2d:
             wp = ops.pack_conv_w_s2d_f16(m.weight.detach())
         else:
@@ -107,9 +110,11 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
             raise ValueError(f"expected {st[0][0].in_channels} input channels, got {x.shape[1]}")
         h0, w0 = x.shape[2], x.shape[3]
         # few input channels: 5x5 s2 over C == 3x3 s1 over the 4C channels of the 2x2 space-to-depth image
+        abs_in = bool(getattr(seq, "abs_input", False))
         s2d_first = (isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
+                     and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in
                      and x.shape[1] <= 4 and h0 % 2 == 0 and w0 % 2 == 0)
-        cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous())
+        cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
     else:
         cur = x_blk
     for idx, (m, g) in enumerate(st):
@@ -128,7 +133,11 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
             cur = _timed(key, lambda: ops.conv5x5s2_s2d_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, h0, w0,
                                                             out_nchw=last, out=out if last else None))
             continue
-        if isinstance(m, nn.ConvTranspose2d):
+        if isinstance(m, nn.Conv2d) and not isinstance(m, nn.ConvTranspose2d) and conv_geometry(m)[:3] == (3, 1, 1):
+            key = ("conv3", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            cur = _timed(key, lambda: ops.conv3x3s1_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
+                                                        out_nchw=last, out=out if last else None))
+        elif isinstance(m, nn.ConvTranspose2d):
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                           out_nchw=last, clamp01=clamp01 and last,

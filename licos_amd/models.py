@@ -29,7 +29,7 @@ class TransformSequential(nn.Sequential):
 
     precision = "fp32"
     abs_input = False   # ScaleHyperprior.h_a consumes |y|
-    fp32_only = False   # hyper transforms (3x3 stride-1 stages) always run on the generic fp32 kernels
+    fp32_only = False   # pins a chain to the generic fp32 kernels whatever the model precision
 
     def forward(self, x):
         if self.precision == "fp16" and not self.fp32_only:
@@ -189,9 +189,9 @@ class FactorizedPriorReLU(FactorizedPrior):
 
 class ScaleHyperprior(CompressionModel):
     """CompressAI ``ScaleHyperprior`` (bmshj2018-hyperprior, BASELINE config 5; allowed by
-    licos/model_utils.py:20-24).  g_a / g_s follow ``precision``; the small hyper transforms h_a / h_s
-    (3x3 stride-1 + 5x5 stride-2 stages on 1/16..1/64-resolution maps, < 3 % of the FLOPs) run on the
-    generic fp32 kernels in either mode."""
+    licos/model_utils.py:20-24).  All four transforms follow ``precision``: on "fp16" the hyper transforms run on
+    the same MFMA kernels (3x3 stride-1 stages as one phase of the transposed-conv kernel, ReLU in the epilogue,
+    |y| folded into the layout conversion)."""
 
     def __init__(self, N, M, precision="fp32", **kwargs):
         super().__init__()
@@ -202,10 +202,8 @@ class ScaleHyperprior(CompressionModel):
         self.h_a = TransformSequential(conv(M, N, stride=1, kernel_size=3), nn.ReLU(inplace=True), conv(N, N),
                                        nn.ReLU(inplace=True), conv(N, N))
         self.h_a.abs_input = True
-        self.h_a.fp32_only = True
         self.h_s = TransformSequential(deconv(N, N), nn.ReLU(inplace=True), deconv(N, N), nn.ReLU(inplace=True),
                                        conv(N, M, stride=1, kernel_size=3), nn.ReLU(inplace=True))
-        self.h_s.fp32_only = True
         self.gaussian_conditional = GaussianConditional(None)
         self.N = int(N)
         self.M = int(M)
@@ -216,8 +214,8 @@ class ScaleHyperprior(CompressionModel):
         return 2 ** (4 + 2)
 
     def _sync_precision(self):
-        self.g_a.precision = self.precision
-        self.g_s.precision = self.precision
+        for t in (self.g_a, self.g_s, self.h_a, self.h_s):
+            t.precision = self.precision
 
     def forward(self, x, noise=None):
         self._sync_precision()

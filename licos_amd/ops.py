@@ -376,11 +376,12 @@ def pack_gdn_bf16(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
     return packed
 
 
-def nchw_f32_to_blk16(x):
+def nchw_f32_to_blk16(x, abs_input=False):
     _dev(x)
     b, c, h, w = x.shape
     y = torch.empty((b, (c + 15) // 16, h, w, 16), device=x.device, dtype=torch.float16)
-    _lib.check(_lib.load().licos_nchw_f32_to_blk16(_p(_f32(x)), _p(y), b, c, h, w, _stream()), "nchw_f32_to_blk16")
+    _lib.check(_lib.load().licos_nchw_f32_to_blk16(_p(_f32(x)), _p(y), b, c, h, w, int(abs_input), _stream()),
+               "nchw_f32_to_blk16")
     return y
 
 
@@ -493,4 +494,32 @@ def deconv5x5s2_fewch_f16(x_blk, w_packed, bias_padded, cin, cout, clamp01=False
     rc = _lib.load().licos_deconv5x5s2_fewch_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(y), int(clamp01), b, cin, h,
                                                  w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_fewch_f16")
+    return y
+
+
+def pack_conv3x3_w_f16(w):
+    _dev(w)
+    cout, cin = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("pack_conv3x3_w_f16: expected a 3x3 kernel")
+    packed = torch.empty(((cin + 15) // 16) * 9 * mfma_tiles(cout) * 512, device=w.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_pack_conv3x3_w_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
+               "pack_conv3x3_w_f16")
+    return packed
+
+
+def conv3x3s1_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, out=None):
+    _dev(x_blk, w_packed, bias_padded, gdn_packed, out)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("conv3x3s1_f16: input is not the blk16 fp16 layout of `cin` channels")
+    if out_nchw:
+        y = _out_nchw(out, (b, cout, h, w), x_blk.device)
+        yb, yn = None, y
+    else:
+        y = torch.empty((b, (cout + 15) // 16, h, w, 16), device=x_blk.device, dtype=torch.float16)
+        yb, yn = y, None
+    rc = _lib.load().licos_conv3x3s1_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+                                         _p(yn), b, cin, h, w, cout, _stream())
+    _lib.check(rc, "conv3x3s1_f16")
     return y

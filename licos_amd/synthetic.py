@@ -57,6 +57,7 @@ def make_trained_like(net, seed=0, scale_range=(0.02, 2.5), sample=None):
     eb = net.entropy_bottleneck
     c = eb.channels
     lo, hi = scale_range
+    hyper = hasattr(net, "gaussian_conditional")
     sigma = torch.exp(torch.empty(c).uniform_(math.log(lo), math.log(hi), generator=gen))
     # with zero factors the MLP is affine: F(v) = v * prod_i(sum of softplus(matrix_i)) + const.  The
     # stock init makes that slope 1/init_scale; rescale layer 0 per channel to slope 1/sigma_c.
@@ -77,15 +78,33 @@ def make_trained_like(net, seed=0, scale_range=(0.02, 2.5), sample=None):
     eb.biases[-1].copy_((-(med / sigma)).reshape(c, 1, 1).to(dev))
     q = torch.stack((med - t * sigma, med, med + t * sigma), dim=1).reshape(c, 1, 3)
     eb.quantiles.copy_(q.to(dev))
-    # calibrate the last analysis conv so that channel c of y is spread like logistic(med_c, sigma_c)
     if sample is None:
-        sample = tiles(4, net.g_a[0].in_channels, 256, seed=1234, device=dev)
-    last = net.g_a[len(net.g_a) - 1]
-    y = net.g_a(sample)
-    mean = y.mean(dim=(0, 2, 3))
-    std = y.std(dim=(0, 2, 3)).clamp_min(1e-8)
-    gain = (1.8138 * sigma.to(dev)) / std  # std of a logistic = pi/sqrt(3) * scale
-    last.weight.mul_(gain.reshape(-1, 1, 1, 1))
-    last.bias.copy_((last.bias - mean) * gain + med.to(dev))
+        cin = net.g_a[0].in_channels
+        sample = tiles(4, cin, 256, seed=1234, kind="aid" if cin == 3 else "s2", device=dev)
+
+    def calibrate(transform, inp, target_std, target_mean):
+        """Rescale the last conv of `transform` so its output channels have the wanted spread."""
+        last = transform[len(transform) - 1]
+        out = transform(inp)
+        mean = out.mean(dim=(0, 2, 3))
+        std = out.std(dim=(0, 2, 3)).clamp_min(1e-8)
+        gain = target_std.to(dev) / std
+        last.weight.mul_(gain.reshape(-1, 1, 1, 1))
+        last.bias.copy_((last.bias - mean) * gain + target_mean.to(dev))
+
+    if not hyper:
+        # channel c of y spread like logistic(med_c, sigma_c); std of a logistic = pi/sqrt(3) * scale
+        calibrate(net.g_a, sample, 1.8138 * sigma, med)
+    else:
+        # scale hyperprior: y_c ~ N(0, s_c) with s_c log-uniform; h_s answers ~s_c (bias-dominated), z follows
+        # the factorised logistic prior set up above
+        m = net.g_a[len(net.g_a) - 1].out_channels
+        s_y = torch.exp(torch.empty(m).uniform_(math.log(0.15), math.log(4.0), generator=gen))
+        calibrate(net.g_a, sample, s_y, torch.zeros(m))
+        y = net.g_a(sample)
+        calibrate(net.h_a, y, 1.8138 * sigma, med)
+        hs_last = net.h_s[len(net.h_s) - 2]  # conv before the final ReLU
+        hs_last.weight.mul_(0.05)
+        hs_last.bias.copy_(s_y.to(dev))
     net.update(force=True)
     return net

@@ -248,3 +248,22 @@ def test_quality6_topology_fp16():
     with torch.no_grad():
         y32 = net.g_a(x.to(DEV))
     assert rel_err(y32, ref["y"]) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w,relu", [(192, 128, 32, 32, True), (128, 192, 32, 32, True), (128, 192, 8, 8, True),
+                                                (20, 40, 9, 21, False)])
+def test_conv3x3_stage_exact_operands(cin, cout, h, w, relu):
+    """3x3 stride-1 conv (hyperprior h_a[0] / h_s[4]) on the MFMA path, with the ReLU epilogue."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 3, 3, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(torch.abs(x), wt, b, stride=1, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV), abs_input=True)
+    wp = ops.pack_conv3x3_w_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    out = ops.conv3x3s1_f16(xb, wp, bp, None, ops.EPI_RELU if relu else ops.EPI_NONE, cin, cout, out_nchw=True)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-5

@@ -175,7 +175,9 @@ int licos_reduce_sqdiff(const float *a, const float *b, long n, int clamp01, dou
  *
  * symbols: int32, stream b, position i at b*sym_stride_b + i*sym_stride_i.
  * indexes: nullable; same addressing; when NULL the CDF row of position i is
- *          i / plane  (EntropyBottleneck._build_indexes: the channel id).
+ *          i / plane  (EntropyBottleneck._build_indexes: the channel id).  With explicit indexes
+ *          (GaussianConditional) `plane` may carry the number of CDF rows (<= 256) to select the kernel
+ *          that stages the short rows in LDS; 0 selects the generic kernel.
  * cdf [rows][cdf_stride] int32, cdf_len[rows], offset[rows]: device copies of
  *          _quantized_cdf / _cdf_length / _offset.
  * enc_table: device copy of licos_rans_build_enc_table's output.

@@ -355,6 +355,202 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
   if (live && src.over) atomicOr(status, 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Per-element-indexed fast path (GaussianConditional: the CDF row of every symbol is data).  The 64 rows have
+// very different lengths (3 .. ~3100 entries); the short, frequent ones are staged in LDS (as many leading rows
+// as fit IDX_CAP entries, decided by the kernel itself from cdf_len), the long ones stay in global memory.
+// Symbols and row indexes are fetched a batch ahead; the decoder shares the plane kernel's LDS word ring and
+// buffered symbol stores.
+constexpr int IDX_CAP = 2560, IDX_MAX_ROWS = 256;
+
+struct IdxTables {
+  int *s_len, *s_off, *s_base;  // [rows] cdf length, symbol offset, first staged entry (or -1)
+};
+
+__device__ inline void idx_stage_rows(int rows, const int32_t *cdf_len, const int32_t *offset, int *s_len, int *s_off,
+                                      int *s_base, int lane) {
+  for (int r = lane; r < rows; r += 64) { s_len[r] = cdf_len[r]; s_off[r] = offset[r]; }
+  __syncthreads();
+  if (lane == 0) {
+    int used = 0;
+    for (int r = 0; r < rows; ++r) {
+      if (used >= 0 && used + s_len[r] <= IDX_CAP) { s_base[r] = used; used += s_len[r]; }
+      else { s_base[r] = -1; used = -1; }  // only a leading run of rows is staged
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void rans_encode_indexed_kernel(const int32_t *__restrict__ symbols,
+                                                                 const int32_t *__restrict__ indexes, long ssb, long ssi, int n,
+                                                                 int rows, int cdf_stride, const int32_t *__restrict__ cdf_len,
+                                                                 const int32_t *__restrict__ offset,
+                                                                 const EncRec *__restrict__ table, uint32_t *__restrict__ words,
+                                                                 int cap_words, int32_t *__restrict__ nwords,
+                                                                 int32_t *__restrict__ status, int B) {
+  __shared__ int s_len[IDX_MAX_ROWS], s_off[IDX_MAX_ROWS], s_base[IDX_MAX_ROWS];
+  __shared__ __attribute__((aligned(16))) EncRec s_tab[IDX_CAP];
+  const int lane = threadIdx.x;
+  const int b_raw = blockIdx.x * 64 + lane;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;
+  idx_stage_rows(rows, cdf_len, offset, s_len, s_off, s_base, lane);
+  for (int r = 0; r < rows; ++r) {
+    const int base = s_base[r];
+    if (base < 0) break;
+    for (int e = lane; e < s_len[r] - 1; e += 64) s_tab[base + e] = table[(size_t)r * cdf_stride + e];
+  }
+  __syncthreads();
+  WordSink sink{words, B, b, cap_words, false};
+  uint64_t x = RANS_L;
+  const int32_t *sp = symbols + (size_t)b * ssb;
+  const int32_t *ip = indexes + (size_t)b * ssb;
+  int32_t sv_next[SYM_BATCH], iv_next[SYM_BATCH];
+  auto fetch = [&](int i1) {
+#pragma unroll
+    for (int k = 0; k < SYM_BATCH; ++k) {
+      const int i = i1 - 1 - k;
+      sv_next[k] = (i >= 0) ? sp[(size_t)i * ssi] : 0;
+      iv_next[k] = (i >= 0) ? ip[(size_t)i * ssi] : 0;
+    }
+  };
+  fetch(n);
+  for (int i1 = n; i1 > 0; i1 -= SYM_BATCH) {
+    const int nb = i1 < SYM_BATCH ? i1 : SYM_BATCH;
+    int32_t sv[SYM_BATCH], mx[SYM_BATCH];
+    EncRec rec[SYM_BATCH];
+#pragma unroll
+    for (int k = 0; k < SYM_BATCH; ++k) {
+      const int c = iv_next[k];
+      mx[k] = s_len[c] - 2;
+      sv[k] = sv_next[k] - s_off[c];
+      const int32_t v = (sv[k] < 0 || sv[k] >= mx[k]) ? mx[k] : sv[k];
+      const int base = s_base[c];
+      rec[k] = (base >= 0) ? s_tab[base + v] : table[(size_t)c * cdf_stride + v];
+    }
+    if (i1 - SYM_BATCH > 0) fetch(i1 - SYM_BATCH);
+#pragma unroll
+    for (int k = 0; k < SYM_BATCH; ++k) {
+      if (k >= nb) break;
+      const int32_t value = sv[k];
+      if (value < 0 || value >= mx[k]) {
+        const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - mx[k]));
+        int nbyp = 0;
+        while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+        if (live) {
+          for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+          put_bits4(x, sink, (uint32_t)nbyp);
+        }
+      }
+      const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
+      if (x >= ((uint64_t)freq << 47)) {
+        if (live) sink.put((uint32_t)x);
+        x >>= 32;
+      }
+      const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
+      x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
+    }
+  }
+  if (live) {
+    sink.put((uint32_t)(x >> 32));
+    sink.put((uint32_t)x);
+    nwords[b] = cap_words - sink.wp;
+    if (sink.overflow) atomicOr(status, 1);
+  }
+}
+
+__global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *__restrict__ in,
+                                                                 const int64_t *__restrict__ byte_off,
+                                                                 const int32_t *__restrict__ indexes, long ssb, long ssi, int n,
+                                                                 int rows, const int32_t *__restrict__ cdf, int cdf_stride,
+                                                                 const int32_t *__restrict__ cdf_len,
+                                                                 const int32_t *__restrict__ offset, int32_t *__restrict__ symbols,
+                                                                 int32_t *__restrict__ status, int B) {
+  __shared__ int s_len[IDX_MAX_ROWS], s_off[IDX_MAX_ROWS], s_base[IDX_MAX_ROWS];
+  __shared__ uint32_t s_cdf[IDX_CAP];
+  __shared__ uint32_t s_ring[RING * 64];
+  __shared__ int32_t s_out[SYM_BUF * 64];
+  const int lane = threadIdx.x;
+  const int b_raw = blockIdx.x * 64 + lane;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;
+  idx_stage_rows(rows, cdf_len, offset, s_len, s_off, s_base, lane);
+  for (int r = 0; r < rows; ++r) {
+    const int base = s_base[r];
+    if (base < 0) break;
+    for (int e = lane; e < s_len[r]; e += 64) s_cdf[base + e] = (uint32_t)cdf[(size_t)r * cdf_stride + e];
+  }
+  __syncthreads();
+  RingSource src;
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane);
+  uint64_t x = (uint64_t)src.next();
+  x |= (uint64_t)src.next() << 32;
+  int32_t *sp = symbols + (size_t)b * ssb;
+  const int32_t *ip = indexes + (size_t)b * ssb;
+  int32_t iv_next[SYM_BUF];
+  auto fetch = [&](int i0) {
+#pragma unroll
+    for (int k = 0; k < SYM_BUF; ++k) iv_next[k] = (i0 + k < n) ? ip[(size_t)(i0 + k) * ssi] : 0;
+  };
+  fetch(0);
+  for (int i0 = 0; i0 < n; i0 += SYM_BUF) {
+    int32_t iv[SYM_BUF];
+#pragma unroll
+    for (int k = 0; k < SYM_BUF; ++k) iv[k] = iv_next[k];
+    if (i0 + SYM_BUF < n) fetch(i0 + SYM_BUF);
+    const int nb = (n - i0) < SYM_BUF ? (n - i0) : SYM_BUF;
+#pragma unroll
+    for (int k = 0; k < SYM_BUF; ++k) {
+      if (k >= nb) break;
+      src.refill_if_low();
+      const int c = iv[k];
+      const int len = s_len[c];
+      const int32_t max_value = len - 2;
+      const int base = s_base[c];
+      const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+      int lo = 0, hi = len - 1;  // row[lo] <= cf < row[hi]
+      uint32_t vlo, vhi;
+      if (base >= 0) {
+        const uint32_t *row = s_cdf + base;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (row[mid] <= cf) lo = mid; else hi = mid;
+        }
+        vlo = row[lo];
+        vhi = row[lo + 1];
+      } else {
+        const int32_t *row = cdf + (size_t)c * cdf_stride;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+        }
+        vlo = (uint32_t)row[lo];
+        vhi = (uint32_t)row[lo + 1];
+      }
+      x = (uint64_t)(vhi - vlo) * (x >> 16) + cf - vlo;
+      if (x < RANS_L) x = (x << 32) | src.next();
+      int32_t value = lo;
+      if (value == max_value) {
+        uint32_t val = get_bits4p(x, src);
+        int nbp = (int)val;
+        while (val == 15u && nbp < 64) { val = get_bits4p(x, src); nbp += (int)val; }
+        uint32_t raw = 0;
+        for (int j = 0; j < nbp; ++j) {
+          const uint32_t nib = get_bits4p(x, src);
+          if (j < 8) raw |= nib << (j * 4);
+        }
+        value = (int32_t)(raw >> 1);
+        value = (raw & 1u) ? -value - 1 : value + max_value;
+      }
+      s_out[k * 64 + lane] = value + s_off[c];
+    }
+    if (live)
+      for (int k = 0; k < nb; ++k) sp[(size_t)(i0 + k) * ssi] = s_out[k * 64 + lane];
+  }
+  if (live && src.over) atomicOr(status, 1);
+}
+
 }  // namespace licos
 
 using namespace licos;
@@ -373,6 +569,11 @@ int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long
     hipLaunchKernelGGL(rans_encode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * sizeof(EncRec),
                        as_stream(stream), symbols, ssb, ssi, n / plane, plane, cdf_stride, cdf_len, offset,
                        static_cast<const EncRec *>(enc_table), words, cap_words, nwords, status, B);
+  } else if (indexes && plane > 0 && plane <= IDX_MAX_ROWS) {
+    // with explicit indexes `plane` carries the number of CDF rows (see licos_hip.h)
+    hipLaunchKernelGGL(rans_encode_indexed_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), symbols, indexes, ssb,
+                       ssi, n, plane, cdf_stride, cdf_len, offset, static_cast<const EncRec *>(enc_table), words, cap_words,
+                       nwords, status, B);
   } else {
     hipLaunchKernelGGL(rans_encode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), symbols, indexes, ssb,
                        ssi, n, plane, cdf_stride, cdf_len, offset, static_cast<const EncRec *>(enc_table), words,
@@ -404,6 +605,9 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
     hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);
+  } else if (indexes && plane > 0 && plane <= IDX_MAX_ROWS) {
+    hipLaunchKernelGGL(rans_decode_indexed_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), in, byte_off, indexes,
+                       ssb, ssi, n, plane, cdf, cdf_stride, cdf_len, offset, symbols, status, B);
   } else {
     hipLaunchKernelGGL(rans_decode_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), in, byte_off, indexes,
                        ssb, ssi, n, plane, cdf, cdf_stride, cdf_len, offset, symbols, status, B);

@@ -450,12 +450,13 @@ class GaussianConditional(nn.Module):
         b = inputs.shape[0]
         n = inputs[0].numel()
         cdf, cdf_len, offset, table = self.coder_tables()
+        rows_hint = cdf.shape[0] if cdf.shape[0] <= 256 else 0  # selects the LDS-staged indexed coder kernels
         zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
         sym = torch.empty((n, b), device=inputs.device, dtype=torch.int32)
         ops.eb_quantize(inputs.contiguous(), zeros, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=b)
         cap = n // 2 + 64
         for attempt in range(2):
-            words, nwords, status = ops.rans_encode_batch(sym, 1, b, n, 0, cdf, cdf_len, offset, table, cap, b,
+            words, nwords, status = ops.rans_encode_batch(sym, 1, b, n, rows_hint, cdf, cdf_len, offset, table, cap, b,
                                                           indexes=indexes_interleaved)
             host = torch.cat((nwords, status)).cpu().numpy()
             if host[-1] == 0:
@@ -478,8 +479,8 @@ class GaussianConditional(nn.Module):
         cdf, cdf_len, offset, _ = self.coder_tables()
         data, byte_off = EntropyBottleneck.pack_strings(strings, cdf.device)
         sym = torch.empty((n, b), device=cdf.device, dtype=torch.int32)
-        status = ops.rans_decode_batch(data, byte_off, 1, b, n, 0, cdf, cdf_len, offset, sym, b,
-                                       indexes=indexes_interleaved)
+        status = ops.rans_decode_batch(data, byte_off, 1, b, n, cdf.shape[0] if cdf.shape[0] <= 256 else 0, cdf, cdf_len,
+                                       offset, sym, b, indexes=indexes_interleaved)
         zeros = torch.zeros(c, device=cdf.device, dtype=torch.float32)
         out = ops.eb_dequantize(sym, 1, b, zeros, b, c, h, w)
         if int(status.item()) != 0:

@@ -1,5 +1,6 @@
 // 16-bit MFMA path (gfx950): 5x5 stride-2 Conv2d (+GDN) and ConvTranspose2d (+IGDN) as LDS-tiled
-// implicit GEMMs on v_mfma_f32_32x32x16_f16, fp32 accumulate.
+// implicit GEMMs on v_mfma_f32_32x32x16_f16, fp32 accumulate.  Shared by mfma_conv.hip, mfma_deconv.hip and
+// mfma_pack.hip.
 //
 // Orientation: D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel], k = (cin chunk of 16, tap, cin in
 // chunk).  Weights are the MFMA A operand, activations the B operand, so an accumulator tile holds
@@ -7,15 +8,14 @@
 //   * the GDN norm  beta_i + sum_j gamma[i][j] x_j^2  is a second MFMA GEMM that takes the squared
 //     accumulator tile as its B operand with no lane movement (MI355X guide, "accumulator tile as
 //     the next MFMA's operand"): gamma is pre-packed k-permuted to match;
-//   * a lane stores 4 consecutive channels of one pixel (8 B) into the blk16 layout.
+//   * a lane stores 8 consecutive channels of one pixel (16 B after one v_permlane32_swap per dword).
 //
 // Activations between stages: blk16 = [B][C/16][H][W][16] fp16 (32 B per pixel per 16-channel chunk).
-// A workgroup (4 waves) owns 256 (NT=2) or 128 (NT=1) output pixels x all output channels; wave w
-// owns NT pixel-tiles of 32.  The K loop walks cin chunks; per chunk the input patch (with halo)
-// sits in LDS as 16-B granules [half][row][x-parity][x/2] (conv) or [half][row][x] (deconv) so
-// that the 32 lanes of a B-fragment read (consecutive output x) hit consecutive granules:
-// conflict-free ds_read_b128.  Weight slabs (one kernel row of 5 taps for conv, the taps of one
-// output phase for deconv) are staged in LDS in fragment order and shared by the 4 waves.
+// A workgroup (4 waves) owns 256 (NT=2) or 128 (NT=1) output pixels x all output channels; wave w owns NT
+// pixel-tiles of 32.  The K loop walks (cin chunk) x (kernel row); each step's input rows and weight
+// fragments arrive by LDS-DMA into the buffer the next step reads (see ConvStepGeom / DeconvStepGeom).
+// LDS granules (16 B = 8 channels of a pixel) are arranged so the 32 lanes of a B-fragment read
+// (consecutive output x) hit consecutive granules: conflict-free ds_read_b128.
 #pragma once
 #include "common.hpp"
 
@@ -31,14 +31,6 @@ constexpr int EPI_NONE = LICOS_EPI_NONE, EPI_GDN = LICOS_EPI_GDN, EPI_IGDN = LIC
 __host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---- geometry shared by host and device ---------------------------------------------------------
-template <int TH, int TW>
-struct ConvGeom {  // stride-2 5x5 conv: output tile TH x TW, input patch (2TH+3) x (2TW+3)
-  static constexpr int PH = 2 * TH + 3;
-  static constexpr int PW = 2 * TW + 3;
-  static constexpr int PWH = round_up(TW + 2, 4);  // granules per (row, parity); %4 keeps 16-wide tiles conflict-free
-  static constexpr int HALF = PH * 2 * PWH;        // granules per 8-channel half
-  static constexpr int PATCH_BYTES = 2 * HALF * 16;
-};
 // Double-buffered stride-2 conv (mfma_conv.hip): per K-step (cin chunk, kernel row ky) only the TH input
 // rows 2*ty + ky that step reads are staged, as granules [half][ty][x-parity][x/2].
 template <int MT, int TH, int TW>

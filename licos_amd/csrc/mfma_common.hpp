@@ -237,6 +237,7 @@ static inline int mt_for(int Cout) {
 
 // defined in mfma_conv.hip / mfma_deconv.hip
 int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
+int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv8.hip; 1 = not applicable
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 

@@ -152,6 +152,12 @@ static int dispatch_tile(const MfmaArgs &a, int width, hipStream_t s) {
 }
 
 int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s) {
+  // wide maps: the 8-wave parity-plane variant (mfma_conv8.hip); LICOS_CONV8=0 keeps the 4-wave kernel for A/B runs
+  static const bool use_conv8 = [] { const char *e = getenv("LICOS_CONV8"); return !(e && e[0] == '0'); }();
+  if (use_conv8) {
+    const int rc = mfma_try_conv8(a, MT, epi, s);
+    if (rc <= 0) return rc;
+  }
   if (MT == 1 && epi == EPI_NONE) return dispatch_tile<1, EPI_NONE>(a, width, s);
   if (MT == 4 && epi == EPI_NONE) return dispatch_tile<4, EPI_NONE>(a, width, s);
   if (MT == 4 && epi == EPI_GDN) return dispatch_tile<4, EPI_GDN>(a, width, s);

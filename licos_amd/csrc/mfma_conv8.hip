@@ -1,0 +1,188 @@
+// MFMA stride-2 5x5 convolution, 8-wave variant for wide maps (output >= 16 x 32): a workgroup owns a
+// 16 x 32 output tile (512 pixels) x all output channels; wave w owns output rows 2w, 2w+1 (NT = 2).
+//
+// Compared with mfma_conv.hip (4 waves, 2 workgroups per CU, the input rows of every kernel row re-staged):
+//   * the input patch of a cin chunk is staged ONCE, as two "parity planes" - the 18 even and the 17 odd
+//     input rows of the tile - because kernel rows 0, 2, 4 read only even rows (row 2*ty + ky, as slot
+//     ty + ky/2 of the even plane) and kernel rows 1, 3 only odd ones.  The K loop visits kernel rows in the
+//     order 0, 2, 4, 1, 3: while the three even steps run, the odd plane of the same chunk is DMA'd in; while
+//     the two odd steps run, the even plane of the NEXT chunk is.  Each plane is single-buffered.
+//   * the weight fragments of a step (double-buffered) are shared by 8 waves instead of 4.
+// Together the LDS-DMA pieces per MFMA drop by ~55 %, which is what the 4-wave kernel's ablation says it is
+// paying for.  One workgroup per CU, two waves per SIMD, one s_barrier per step.
+#include "mfma_common.hpp"
+
+namespace licos {
+
+template <int MT>
+struct Conv8Geom {
+  static constexpr int TH = 16, TW = 32, NT = 2;
+  static constexpr int PWH = 36, ROWG = 2 * PWH;           // granules per (half, row): both x parities
+  static constexpr int NR_E = TH + 2, NR_O = TH + 1;       // even / odd input rows of the tile
+  static constexpr int EVEN_GRAN = 2 * NR_E * ROWG;        // 2592
+  static constexpr int ODD_GRAN = 2 * NR_O * ROWG;         // 2448
+  static constexpr int W_GRAN = 5 * MT * 64;
+  static constexpr int EVEN_Q = (EVEN_GRAN + 63) / 64, ODD_Q = (ODD_GRAN + 63) / 64, W_Q = W_GRAN / 64;
+  static constexpr int EVEN_PAD = EVEN_Q * 64, ODD_PAD = ODD_Q * 64;
+  static constexpr int TOTAL_GRAN = EVEN_PAD + ODD_PAD + 2 * W_GRAN;
+  static constexpr int GAMMA_GRAN = MT * MT * 2 * 64;
+  static constexpr int LDS_BYTES = 16 * (TOTAL_GRAN > GAMMA_GRAN ? TOTAL_GRAN : GAMMA_GRAN);
+  static constexpr int NPE = (EVEN_Q + 7) / 8, NPO = (ODD_Q + 7) / 8, NPW = (W_Q + 7) / 8;  // pieces per wave
+  static constexpr int ODD_PER_STEP = (ODD_Q + 2) / 3, EVEN_PER_STEP = (EVEN_Q + 1) / 2;
+};
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
+  using G = Conv8Geom<MT>;
+  constexpr int NT = G::NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_even = reinterpret_cast<half8 *>(smem);
+  half8 *s_odd = s_even + G::EVEN_PAD;
+  half8 *s_wbuf = s_odd + G::ODD_PAD;  // [2][W_GRAN]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int oy0 = (tile / a.tiles_x) * G::TH, ox0 = (tile % a.tiles_x) * G::TW;
+  const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
+
+  int base_e[NT], base_o[NT], oy[NT], ox[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ty = wave * NT + nt;
+    oy[nt] = oy0 + ty;
+    ox[nt] = ox0 + r;
+    base_e[nt] = h * (G::NR_E * G::ROWG) + ty * G::ROWG + r;
+    base_o[nt] = h * (G::NR_O * G::ROWG) + ty * G::ROWG + r;
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
+
+  const size_t plane = (size_t)a.H * a.W;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
+
+  // per-lane source offset (half8 units inside a chunk plane) of this wave's patch pieces; -1 = outside the image
+  int e_off[G::NPE], o_off[G::NPO];
+  auto piece_offset = [&](int q, int nrows, int row_parity, int limit) {
+    const int d = q * 64 + lane;
+    if (d >= limit) return -1;
+    const int hh = d / (nrows * G::ROWG), rem = d - hh * (nrows * G::ROWG);
+    const int j = rem / G::ROWG, r2 = rem - j * G::ROWG;
+    const int par = r2 / G::PWH, xh = r2 - par * G::PWH;
+    const int iy = iy0 + 2 * j + row_parity, ix = ix0 + 2 * xh + par;
+    if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) return -1;
+    return (iy * a.W + ix) * 2 + hh;
+  };
+#pragma unroll
+  for (int i = 0; i < G::NPE; ++i) e_off[i] = piece_offset(wave + 8 * i, G::NR_E, 0, G::EVEN_GRAN);
+#pragma unroll
+  for (int i = 0; i < G::NPO; ++i) o_off[i] = piece_offset(wave + 8 * i, G::NR_O, 1, G::ODD_GRAN);
+
+  // DMA helpers: pieces [q_lo, q_hi) of a plane / the weight slab of one kernel row
+  auto dma_even = [&](int cc, int q_lo, int q_hi) {
+    const half8 *xin = xb + (size_t)cc * plane * 2;
+#pragma unroll
+    for (int i = 0; i < G::NPE; ++i) {
+      const int q = wave + 8 * i;
+      if (q >= q_lo && q < q_hi && q < G::EVEN_Q) glds16(e_off[i] >= 0 ? xin + e_off[i] : zero, s_even + q * 64);
+    }
+  };
+  auto dma_odd = [&](int cc, int q_lo, int q_hi) {
+    const half8 *xin = xb + (size_t)cc * plane * 2;
+#pragma unroll
+    for (int i = 0; i < G::NPO; ++i) {
+      const int q = wave + 8 * i;
+      if (q >= q_lo && q < q_hi && q < G::ODD_Q) glds16(o_off[i] >= 0 ? xin + o_off[i] : zero, s_odd + q * 64);
+    }
+  };
+  auto dma_w = [&](int cc, int ky, int buf) {
+    const half8 *wsrc = a.wp + (size_t)(cc * 5 + ky) * G::W_GRAN + lane;
+#pragma unroll
+    for (int i = 0; i < G::NPW; ++i) {
+      const int q = wave + 8 * i;
+      if (q < G::W_Q) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN + q * 64);
+    }
+  };
+
+  dma_even(0, 0, G::EVEN_Q);
+  dma_w(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int wcur = 0;
+  for (int cc = 0; cc < a.Cin16; ++cc) {
+#pragma unroll
+    for (int si = 0; si < 5; ++si) {
+      const int ky = (si < 3) ? 2 * si : 2 * si - 5;  // 0, 2, 4, 1, 3
+      // prefetch: next step's weights, and a share of the plane that is not being read
+      if (si < 4) dma_w(cc, (si + 1 < 3) ? 2 * (si + 1) : 2 * (si + 1) - 5, wcur ^ 1);
+      else if (cc + 1 < a.Cin16) dma_w(cc + 1, 0, wcur ^ 1);
+      if (si < 3) dma_odd(cc, si * G::ODD_PER_STEP, (si + 1) * G::ODD_PER_STEP);
+      else if (cc + 1 < a.Cin16) dma_even(cc + 1, (si - 3) * G::EVEN_PER_STEP, (si - 2) * G::EVEN_PER_STEP);
+      const half8 *s_patch = (si < 3) ? s_even : s_odd;
+      const half8 *s_w = s_wbuf + wcur * G::W_GRAN;
+      const int rowoff = (ky >> 1) * G::ROWG;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        half8 bf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bf[nt] = s_patch[((si < 3) ? base_e[nt] : base_o[nt]) + rowoff + (kx & 1) * G::PWH + (kx >> 1)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const half8 af = s_w[(kx * MT + mt) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      wcur ^= 1;
+    }
+  }
+  const bf16x8 *gam = a.gamma;
+  if (EPI == EPI_GDN || EPI == EPI_IGDN) {
+    bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
+    for (int g = tid; g < G::GAMMA_GRAN; g += 512) s_gamma[g] = a.gamma[g];
+    __syncthreads();
+    gam = s_gamma;
+  }
+  epilogue_store<MT, NT, EPI>(acc, a, gam, b, oy, ox, lane);
+}
+
+template <int MT, int EPI>
+static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
+  using G = Conv8Geom<MT>;
+  MfmaArgs a = a0;
+  a.tiles_x = cdiv(a.Wo, G::TW);
+  a.tiles_y = cdiv(a.Ho, G::TH);
+  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::TOTAL_GRAN * 16;
+  auto kern = conv5x5s2_mfma8_kernel<MT, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(512), lds, s, a);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+// returns LICOS_OK after launching, or 1 when this variant does not apply (caller falls back to the 4-wave kernel)
+int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
+  if (MT != 4 || a.Ho < 16 || a.Wo < 32 || (a.Ho % 16) != 0) return 1;
+  if (epi == EPI_GDN) return launch_conv8<4, EPI_GDN>(a, s);
+  if (epi == EPI_NONE) return launch_conv8<4, EPI_NONE>(a, s);
+  if (epi == EPI_RELU) return launch_conv8<4, EPI_RELU>(a, s);
+  return 1;
+}
+
+}  // namespace licos

@@ -145,30 +145,33 @@ def main():
     psnr = licos_amd.metrics.compute_psnr(dec["x_hat"], x)
 
     stages = {}
-    roof = None
+    roof = roof_d2 = None
     if events:
-        a3 = None
-        for key, evs in events.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-            fl = stage_flops(*key[:5]) * key[5]
-            stages["%s_%d_%d_%dx%d_b%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
-            if key[:5] == ("conv", 128, 128, 128, 128) and (a3 is None or key[5] > a3[5]):
-                a3 = key
-        if a3 is not None:
-            key, LB = a3, a3[5]
+        # the two MFMA kernels the time goes to: g_a[2] (SURVEY.md section 8(d)'s target kernel, `roofline`) and
+        # g_s[2], the largest single kernel of the step (`roofline_g_s2`); same algorithmic FLOPs per tile
+        def roofline_of(kind, kernel_name, traffic_file):
+            keys = [k for k in events if k[:5] == (kind, 128, 128, 128 if kind == "conv" else 64, 128 if kind == "conv" else 64)]
+            if not keys:
+                return None
+            key = max(keys, key=lambda k: k[5])
+            LB = key[5]
             ms = sum(e0.elapsed_time(e1) for e0, e1 in events[key]) / len(events[key])
             ach = FLOP_PER_TILE_A3 * LB / (ms * 1e-3) / 1e12
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv_a3.json")
+            tfile = os.path.join(ROOT, "profiles", traffic_file)
             if os.path.exists(tfile):  # PMC passes cannot run inside the timed process; see profiles/README.md
                 tj = json.load(open(tfile))
                 traffic = tj["hbm_bytes_per_launch"] * LB / tj["tiles_per_launch"]
-            roof = {"kernel": "conv5x5s2_mfma_kernel<4,2,8,32,GDN> (g_a[2], 128->128 @128^2->64^2)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_traffic_conv_a3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, scaled to this launch size)", "avg_launch_ms": round(ms, 4),
-                    "launches": len(events[key]), "tiles_per_launch": LB,
-                    "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB}
+            return {"kernel": kernel_name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, scaled "
+                                      "to this launch size)" % traffic_file,
+                    "avg_launch_ms": round(ms, 4), "launches": len(events[key]), "tiles_per_launch": LB,
+                    "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB,
+                    "algorithmic_bytes_per_launch": 5242880 * LB}
+        roof = roofline_of("conv", "conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r01_pmc_traffic_conv_a3.json")
+        roof_d2 = roofline_of("deconv", "deconv5x5s2_mfma_kernel<4,2,8,32,IGDN> (g_s[2], 128->128 @64^2->128^2)",
+                              "r01_pmc_traffic_deconv_s2.json")
 
     # federated weight averaging step: one RCCL all-reduce of the flat fp32 state
     fed = None
@@ -212,7 +215,7 @@ def main():
                                                                               args.channels, args.size, args.size, B),
                        "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": "synthetic trained-like (seeded)"},
             "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
-            "roofline": roof, "cpu_baseline": cpu, "fedavg_allreduce": fed, "stages": stages,
+            "roofline": roof, "roofline_g_s2": roof_d2, "cpu_baseline": cpu, "fedavg_allreduce": fed, "stages": stages,
         }
         print(json.dumps(line))
     if world > 1:

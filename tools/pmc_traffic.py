@@ -1,0 +1,44 @@
+"""Dev tool: turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command)
+into a per-launch HBM-traffic JSON for one kernel.
+
+  python tools/pmc_traffic.py FETCH.csv WRITE.csv KERNEL_SUBSTRING TILES_PER_LAUNCH ALGORITHMIC_BYTES_PER_TILE OUT.json
+
+Dispatches are selected by kernel-name substring and, among those, the largest Grid_Size (the full-size
+launches of the stage in question).  Units/corrections follow MI355X_MICROARCH.md (HBM / rocprofv3 section):
+both counters are in KB; on gfx950 FETCH_SIZE books a 128-B request as 64 B, so it is doubled; WRITE_SIZE
+is taken as is."""
+import csv, json, sys
+
+
+def collect(path, counter, needle):
+    rows = []
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+                rows.append((int(r["Grid_Size"]), float(r["Counter_Value"]), r["Kernel_Name"]))
+    if not rows:
+        raise SystemExit(f"no {counter} rows for kernels matching {needle!r} in {path}")
+    gmax = max(g for g, _, _ in rows)
+    vals = [v for g, v, _ in rows if g == gmax]
+    return gmax, vals, rows[0][2]
+
+
+def main():
+    fetch_csv, write_csv, needle, tiles, alg_per_tile, out = sys.argv[1:7]
+    g1, fetch, name = collect(fetch_csv, "FETCH_SIZE", needle)
+    g2, write, _ = collect(write_csv, "WRITE_SIZE", needle)
+    assert g1 == g2, (g1, g2)
+    f_kb = sum(fetch) / len(fetch)
+    w_kb = sum(write) / len(write)
+    res = {"kernel": name.split("(")[0].replace("void ", ""), "tiles_per_launch": int(tiles), "grid_threads": g1,
+           "FETCH_SIZE_KB_raw_mean": f_kb, "WRITE_SIZE_KB_mean": w_kb, "dispatches": len(fetch),
+           "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
+           "hbm_read_bytes_per_launch": 2 * f_kb * 1024, "hbm_write_bytes_per_launch": w_kb * 1024,
+           "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
+           "algorithmic_bytes_per_launch": float(alg_per_tile) * int(tiles)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -92,21 +92,36 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
     if (s + 1 < S) stage(s + 1, cur ^ 1);
     const half8 *s_patch = s_buf + cur * G::BUF_GRAN;
     const half8 *s_w = s_patch + G::PATCH_GRAN;
+    // LDS reads run one item (one A fragment = NT MFMAs) ahead of their use, pinned by sched_group_barrier, so
+    // the LDS latency sits under the previous item's MFMAs instead of in front of its own
+    auto taps = [&](auto first_c, auto count_c) {  // taps [FIRST, FIRST + COUNT) of this kernel row
+      constexpr int FIRST = decltype(first_c)::value, NI = decltype(count_c)::value * MT;
+      half8 bf[NT], af = s_w[FIRST * MT * 64 + lane];
 #pragma unroll
-    for (int ikx = 0; ikx < 3; ++ikx) {
-      if (ikx < nkx) {  // wave-uniform: odd-x phases have 2 taps per kernel row
-        half8 bf[NT];
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + (1 - FIRST)];  // dx = (px + 2 - kx) / 2 = 1 - ikx
+      static_for<NI>([&](auto itc) {
+        constexpr int it = decltype(itc)::value, ikx = FIRST + it / MT, mt = it % MT;
+        constexpr bool next_tap = (mt == MT - 1 && it + 1 < NI);
+        half8 af_n = af, bf_n[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = s_patch[base[nt] + (1 - ikx)];  // dx = (px + 2 - kx) / 2 = 1 - ikx
+        for (int nt = 0; nt < NT; ++nt) bf_n[nt] = bf[nt];
+        if (it + 1 < NI) af_n = s_w[(FIRST * MT + it + 1) * 64 + lane];
+        if (next_tap) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const half8 af = s_w[(ikx * MT + mt) * 64 + lane];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) bf_n[nt] = s_patch[base[nt] + (1 - (ikx + 1))];
         }
-      }
-    }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, next_tap ? 1 + NT : (it + 1 < NI ? 1 : 0), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        af = af_n;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = bf_n[nt];
+      });
+    };
+    taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    if (nkx == 3) taps(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});  // wave-uniform: even-x phases
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

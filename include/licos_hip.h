@@ -158,6 +158,13 @@ int licos_gc_build_indexes(const float *scales, const float *table, int levels, 
  * /root/reference/licos/raw_image_folder.py:192-196 with use_full_range=False: x = DN / 4095 (raw_utils.py:128),
  * then skimage.img_as_ubyte(x) / 255 = rint(x * 255) / 255.  dn: uint16 [n]; out: fp32 [n]. */
 int licos_dn12_to_grid8_f32(const uint16_t *dn, float *out, long n, int full_range, void *stream);
+/* Band resampling of Sentinel-2 granules (/root/reference/licos/raw_utils.py:134-244: image_band_upsample /
+ * image_band_reshape call torch.nn.functional.interpolate(mode="bilinear"), align_corners=True when up-sampling,
+ * the default (False) when down-sampling).  src: [planes][Hin][Win] fp32 -> dst: [planes][Hout][Wout].  scale_h /
+ * scale_w are the source-coordinate steps the caller derives as ATen does: (in-1)/(out-1) with align_corners, else
+ * 1/scale_factor; a dimension with Hin == Hout (Win == Wout) is copied. */
+int licos_resample_bilinear_f32(const float *src, float *dst, long planes, int Hin, int Win, int Hout, int Wout,
+                                float scale_h, float scale_w, int align_corners, void *stream);
 /* Cuts (B, C, H, W) images into T x T tiles (zero padded at the right/bottom edge) laid out as a tile batch
  * (B*ny*nx, C, T, T), and the inverse (crop back).  Whole granules (raw_utils.py:131: up to 2304 x 2592) then
  * ride the batched tile codec instead of one 4.5-M-symbol stream. */
@@ -167,6 +174,14 @@ int licos_untile_f32(const float *tiles, float *img, int B, int C, int H, int W,
 /* mean-squared-error numerator: sum over all elements of (a-b)^2 into *out (double, zeroed by caller);
  * /root/reference/eval_utils.py:145-156, RateDistortionLoss mse term.  clamp01 != 0 clamps `a` first. */
 int licos_reduce_sqdiff(const float *a, const float *b, long n, int clamp01, double *out, void *stream);
+
+/* One scale of MS-SSIM (/root/reference/eval_utils.py:159-169 -> pytorch_msssim.ms_ssim, a dependency absent from
+ * the reference tree): 11-tap window (HOST pointer, 11 floats), "valid" filtering of x, y, x^2, y^2, xy, then
+ * cs = (2 s12 + C2)/(s1 + s2 + C2), ssim = (2 m1 m2 + C1)/(m1^2 + m2^2 + C1) * cs.  x, y: [planes][H][W] fp32;
+ * sums: double [planes][2] (zeroed by the caller) receives the sums of the ssim and cs maps over the
+ * (H-10) x (W-10) valid region. */
+int licos_ssim_stats_f32(const float *x, const float *y, int planes, int H, int W, const float *window11, float C1, float C2,
+                         double *sums, void *stream);
 
 /* ------------------------------------------------------------------- rANS
  * CompressAI cpp_exts/rans/rans_interface.cpp RansEncoder.encode_with_indexes /

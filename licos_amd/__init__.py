@@ -3,7 +3,7 @@ hot path: bmshj2018-factorized analysis/synthesis transforms, entropy bottleneck
 bit-exact rANS stream, behind CompressAI's nn.Module surface.  See DESIGN.md."""
 from .entropy_models import EntropyBottleneck, GaussianConditional  # noqa: F401
 from .layers import GDN  # noqa: F401
-from . import metrics  # noqa: F401
+from . import checkpoint, metrics  # noqa: F401
 from .losses import RateDistortionLoss  # noqa: F401
 from .model_utils import get_model  # noqa: F401
 from .models import FactorizedPrior, FactorizedPriorReLU, ScaleHyperprior  # noqa: F401

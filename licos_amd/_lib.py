@@ -35,12 +35,14 @@ SIGNATURES = {
     "licos_eb_likelihood": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
     "licos_eb_dequantize": (_i, [_vp, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_reduce_sqdiff": (_i, [_vp, _vp, _l, _i, _vp, _vp]),
+    "licos_ssim_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _vp, _vp]),
     "licos_rans_encode_batch": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "licos_rans_compact": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "licos_rans_decode_batch": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "licos_gc_likelihood": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
     "licos_gc_build_indexes": (_i, [_vp, _vp, _i, _f, _vp, _l, _l, _i, _l, _vp]),
     "licos_dn12_to_grid8_f32": (_i, [_vp, _vp, _l, _i, _vp]),
+    "licos_resample_bilinear_f32": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "licos_tile_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_untile_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_scale_f32": (_i, [_vp, _l, _f, _vp, _vp]),

@@ -277,6 +277,73 @@ __global__ __launch_bounds__(256) void reduce_sqdiff_kernel(const float *__restr
   if (threadIdx.x == 0) atomicAdd(out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
+// ---- SSIM statistics of one scale (MS-SSIM metric) ------------------------------------------------------
+// 11-tap Gaussian window, "valid" region, per plane sums of the ssim and cs maps.  A 256-thread block owns a 16x16
+// patch of the (H-10)x(W-10) output map: the 26x26 inputs of both images go to LDS, a horizontal pass leaves the
+// five filtered moments (x, y, xx, yy, xy) for 26 rows x 16 columns, the vertical pass finishes them per thread.
+struct SsimWin { float w[11]; };
+
+__global__ __launch_bounds__(256) void ssim_stats_kernel(const float *__restrict__ x, const float *__restrict__ y, int H, int W,
+                                                         SsimWin win, float C1, float C2, double *__restrict__ sums) {
+  __shared__ float s_in[2][26][27];
+  __shared__ float s_h[5][26][17];
+  __shared__ double s_red[2][4];
+  const int plane = blockIdx.z, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, Ho = H - 10, Wo = W - 10;
+  const float *xp = x + (size_t)plane * H * W, *yp = y + (size_t)plane * H * W;
+  for (int e = threadIdx.x; e < 26 * 26; e += 256) {
+    const int r = e / 26, c = e - r * 26;
+    const int iy = oy0 + r, ix = ox0 + c;
+    const bool in = iy < H && ix < W;
+    s_in[0][r][c] = in ? xp[(size_t)iy * W + ix] : 0.f;
+    s_in[1][r][c] = in ? yp[(size_t)iy * W + ix] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 26 * 16; e += 256) {
+    const int r = e >> 4, c = e & 15;
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float a = s_in[0][r][c + k], b = s_in[1][r][c + k], w = win.w[k];
+      m[0] += w * a;
+      m[1] += w * b;
+      m[2] += w * (a * a);
+      m[3] += w * (b * b);
+      m[4] += w * (a * b);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s_h[q][r][c] = m[q];
+  }
+  __syncthreads();
+  double ssim_v = 0.0, cs_v = 0.0;
+  if (oy0 + ty < Ho && ox0 + tx < Wo) {
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) m[q] += win.w[k] * s_h[q][ty + k][tx];
+    const float mu1_sq = m[0] * m[0], mu2_sq = m[1] * m[1], mu1_mu2 = m[0] * m[1];
+    const float sigma1_sq = m[2] - mu1_sq, sigma2_sq = m[3] - mu2_sq, sigma12 = m[4] - mu1_mu2;
+    const float cs = (2.f * sigma12 + C2) / (sigma1_sq + sigma2_sq + C2);
+    cs_v = (double)cs;
+    ssim_v = (double)(((2.f * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ssim_v += __shfl_down(ssim_v, off, 64);
+    cs_v += __shfl_down(cs_v, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_red[0][wave] = ssim_v;
+    s_red[1][wave] = cs_v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + 2 * plane, s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
+    atomicAdd(sums + 2 * plane + 1, s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+  }
+}
+
 // ---- Gaussian conditional ---------------------------------------------------------------------------
 __device__ inline float std_cumulative(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
 
@@ -321,6 +388,41 @@ __global__ void dn12_to_grid8_kernel(const uint16_t *__restrict__ dn, float *__r
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const double v = (double)dn[e] / 4095.0;
     out[e] = full_range ? (float)v : (float)(rint(v * 255.0) / 255.0);
+  }
+}
+
+// Bilinear resampling of a batch of 2-D planes with torch.nn.functional.interpolate's arithmetic (ATen
+// UpSampleKernel: source index = scale * dst (align_corners) or max(scale * (dst + .5) - .5, 0); i0 = min(int(src),
+// in - 1); l1 = clamp(src - i0, 0, 1); a dimension whose size does not change is copied).
+__device__ inline void bilinear_tap(int dst, int in, int out, float scale, int align, int &i0, int &i1, float &l0, float &l1) {
+  if (in == out) {
+    i0 = i1 = dst;
+    l0 = 1.f;
+    l1 = 0.f;
+    return;
+  }
+  float src = align ? scale * (float)dst : scale * ((float)dst + 0.5f) - 0.5f;
+  if (!align && src < 0.f) src = 0.f;
+  i0 = min((int)src, in - 1);
+  l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l0 = 1.f - l1;
+}
+
+__global__ void resample_bilinear_kernel(const float *__restrict__ src, float *__restrict__ dst, long planes, int Hin, int Win,
+                                         int Hout, int Wout, float scale_h, float scale_w, int align) {
+  const long total = planes * Hout * Wout;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+    const long p = e / ((long)Wout * Hout);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    bilinear_tap(oy, Hin, Hout, scale_h, align, y0, y1, hy0, hy1);
+    bilinear_tap(ox, Win, Wout, scale_w, align, x0, x1, wx0, wx1);
+    const float *s = src + p * (long)Hin * Win;
+    const float top = __fadd_rn(__fmul_rn(wx0, s[(long)y0 * Win + x0]), __fmul_rn(wx1, s[(long)y0 * Win + x1]));
+    const float bot = __fadd_rn(__fmul_rn(wx0, s[(long)y1 * Win + x0]), __fmul_rn(wx1, s[(long)y1 * Win + x1]));
+    dst[e] = __fadd_rn(__fmul_rn(hy0, top), __fmul_rn(hy1, bot));
   }
 }
 
@@ -479,6 +581,17 @@ int licos_dn12_to_grid8_f32(const uint16_t *dn, float *out, long n, int full_ran
   return LICOS_OK;
 }
 
+int licos_resample_bilinear_f32(const float *src, float *dst, long planes, int Hin, int Win, int Hout, int Wout,
+                                float scale_h, float scale_w, int align_corners, void *stream) {
+  LICOS_REQUIRE(src && dst && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "resample_bilinear_f32: bad arguments");
+  const long total = planes * Hout * Wout;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(resample_bilinear_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, planes, Hin, Win, Hout,
+                     Wout, scale_h, scale_w, align_corners);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 static int tile_launch(const float *src, float *dst, int B, int C, int H, int W, int T, int dir, void *stream) {
   LICOS_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && T > 0, "tile: bad arguments");
   const int ny = cdiv(H, T), nx = cdiv(W, T);
@@ -501,6 +614,19 @@ int licos_scale_f32(float *x, long n, float alpha, const float *inv_alpha_dev, v
   LICOS_REQUIRE(x && n > 0, "scale_f32: bad arguments");
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(scale_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, alpha, inv_alpha_dev);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_ssim_stats_f32(const float *x, const float *y, int planes, int H, int W, const float *window11, float C1, float C2,
+                         double *sums, void *stream) {
+  LICOS_REQUIRE(x && y && window11 && sums && planes > 0, "ssim_stats_f32: bad arguments");
+  LICOS_REQUIRE(H >= 11 && W >= 11, "ssim_stats_f32: planes must be at least 11 x 11 (the window)");
+  LICOS_REQUIRE(planes <= 65535, "ssim_stats_f32: too many planes in one call");
+  SsimWin win;
+  for (int k = 0; k < 11; ++k) win.w[k] = window11[k];
+  hipLaunchKernelGGL(ssim_stats_kernel, dim3(cdiv(W - 10, 16), cdiv(H - 10, 16), planes), dim3(256), 0, as_stream(stream), x, y, H, W,
+                     win, C1, C2, sums);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -103,7 +103,28 @@ def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_ti
         vals = torch.stack(allv).cpu()
         coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[dist.get_rank(group)]
     weighted_average_(flat_state, coef, group=group)
+    # the reference leaves the averaged model on disk as the "central model" (federation_utils.py:58-83); with a
+    # collective every rank holds it already, so one rank writes the same file for eval_script.py to pick up
+    save_path = _cfg_get(cfg, "save_path")
+    if save_path:
+        from . import checkpoint
+        r = dist.get_rank(group) if dist.is_initialized() else 0
+        state = None
+        if _cfg_get(cfg, "save_checkpoints_over_time"):
+            state = checkpoint.make_state(net, batch_idx, loss, local_time)
+            checkpoint.save_model_checkpoint_over_time(cfg, local_time, rank, state)
+        if r == 0:
+            checkpoint.save_checkpoint(state or checkpoint.make_state(net, batch_idx, loss, local_time), False,
+                                       filename=save_path + ".pth.tar")
     return flat_state
+
+
+def _cfg_get(cfg, key):
+    if cfg is None:
+        return None
+    if isinstance(cfg, dict):
+        return cfg.get(key)
+    return getattr(cfg, key, None)
 
 
 def clock_sync(running=1, group=None, device=None):

@@ -183,3 +183,46 @@ def test_hyperprior_surface_and_tables():
     net2 = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5)
     net2.load_state_dict(net.state_dict())
     assert torch.equal(net2.gaussian_conditional._quantized_cdf, net.gaussian_conditional._quantized_cdf)
+
+
+def test_stream_container_round_trip(tmp_path):
+    """checkpoint.write_strings / read_strings: length-prefixed container, ragged and empty strings included."""
+    import io
+    from licos_amd import checkpoint
+    out = {"strings": [[b"", b"\x00\x01\x02", bytes(range(256)) * 3], [b"a", b"", b"xyz"]], "shape": (16, 16)}
+    buf = io.BytesIO()
+    checkpoint.write_strings(buf, out)
+    buf.seek(0)
+    back = checkpoint.read_strings(buf)
+    assert back == out
+    with pytest.raises(ValueError):
+        checkpoint.read_strings(io.BytesIO(b"nope" + b"\0" * 16))
+    trunc = io.BytesIO(buf.getvalue()[:-5])
+    with pytest.raises(ValueError):
+        checkpoint.read_strings(trunc)
+    with pytest.raises(ValueError):
+        checkpoint.write_strings(io.BytesIO(), {"strings": [[b"a"], [b"a", b"b"]], "shape": (1, 1)})
+
+
+def test_checkpoint_dict_layout(tmp_path):
+    """The checkpoint file is the reference's dict (federation_utils.py:69-78) and the over-time path follows
+    licos/utils.py:82-111."""
+    import torch
+    from licos_amd import checkpoint
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.arange(4.0))
+
+    net = Net()
+    state = checkpoint.make_state(net, batch_idx=7, loss=0.25, local_time=12.5)
+    assert set(state) == {"batch_idx", "state_dict", "loss", "local_time"}
+    cfg = {"save_path": str(tmp_path / "results" / "modelX")}
+    os.makedirs(tmp_path / "results", exist_ok=True)
+    checkpoint.save_model_checkpoint_over_time(cfg, 12.5, 3, state)
+    expect = tmp_path / "results" / "modelX" / "modelX_time_checkpoints" / "modelX_rank_3_sim_time=12.5.pth.tar"
+    assert expect.exists()
+    back = torch.load(expect, weights_only=False)
+    assert back["batch_idx"] == 7 and back["local_time"] == 12.5
+    assert torch.equal(back["state_dict"]["w"], net.w.detach())

@@ -152,3 +152,20 @@ def test_sequential_federation_closed_form():
     for key in ("w", "b"):
         ref = sum(c * s[key].double() for c, s in zip(coef, states))
         assert torch.allclose(central[key].double(), ref, atol=1e-6)
+
+
+def test_raw_band_geometry_oracle():
+    """oracle/raw.py reproduces the reference's target shapes (raw_utils.py:131) for every band and target."""
+    import numpy as np
+    from oracle import raw as oraw
+    rng = np.random.default_rng(0)
+    for target in (10.0, 20.0):
+        for band in oraw.BAND_LIST[:12]:
+            h, w = oraw.native_shape(band)
+            x = torch.from_numpy(rng.random((h // 8, w // 8), dtype=np.float32))
+            out = oraw.image_band_reshape(x, band, target)
+            assert tuple(out.shape) == (oraw.SHAPES[target][0] // 8, oraw.SHAPES[target][1] // 8), (band, target)
+    # DN -> 8-bit grid: values are multiples of 1/255
+    dn = rng.integers(0, 4096, size=(16, 16), dtype=np.uint16)
+    g = oraw.open_band(dn).numpy().astype(np.float64) * 255
+    assert np.abs(g - np.rint(g)).max() < 1e-4

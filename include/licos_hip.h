@@ -267,6 +267,14 @@ int licos_pack_deconv_w_fewch_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin,
 int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch, const float *bias, float *y_nchw,
                                 int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
 
+/* The same stage for 1..4 output channels (RGB / single-band tiles) in scatter form: one contraction per INPUT pixel
+ * over all 25 taps (one 32-row MFMA tile per output channel), each product added to its output pixel
+ * out[2*iy + ky - 2][2*ix + kx - 2] in an LDS image of the output tile (2^-20 fixed point, order independent). */
+size_t licos_packed_deconv_w_scatter_bytes(int Cin, int Cout);
+int licos_pack_deconv_w_scatter_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scatter, const float *bias, float *y_nchw,
+                                  int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
+
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2

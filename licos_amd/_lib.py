@@ -57,6 +57,9 @@ SIGNATURES = {
     "licos_packed_deconv_w_fewch_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_deconv_w_fewch_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_deconv5x5s2_fewch_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_packed_deconv_w_scatter_bytes": (_c.c_size_t, [_i, _i]),
+    "licos_pack_deconv_w_scatter_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "licos_deconv5x5s2_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_nchw_f32_to_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_pack_conv3x3_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_conv3x3s1_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -7,6 +7,7 @@ reparametrised bf16 gamma fragments) are cached per module and rebuilt when a pa
 version or storage changes - so modules swapped in after construction (model_utils.py:31-45) and
 optimiser steps are picked up lazily.
 """
+import os
 import weakref
 
 import torch
@@ -38,6 +39,9 @@ def _pver(p):
     return None if p is None else (p.data_ptr(), p._version, str(p.device))
 
 
+SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
+
+
 def _packed_conv(m, s2d=False, fewch=False):
     key = (_pver(m.weight), _pver(m.bias), s2d, fewch)
     ent = _cache.get(m)
@@ -49,7 +53,9 @@ def _packed_conv(m, s2d=False, fewch=False):
             raise ValueError("licos_amd: the fp16 MFMA path implements 5x5 stride-2 (de)convolutions and 3x3 "
                              "stride-1 convolutions; use precision='fp32' for other shapes")
         cout = m.out_channels
-        if fewch:
+        if fewch == "scatter":
+            wp = ops.pack_deconv_w_scatter_f16(m.weight.detach())
+        elif fewch:
             wp = ops.pack_deconv_w_fewch_f16(m.weight.detach())
         elif k3:
             wp = ops.pack_conv3x3_w_f16(m.weight.detach())
@@ -120,7 +126,14 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
     for idx, (m, g) in enumerate(st):
         last = idx == len(st) - 1
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
+        if fewch and SCATTER_LAST and m.out_channels <= 4 and m.in_channels in (128, 192):
+            fewch = "scatter"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
+        if fewch == "scatter":
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            cur = _timed(key, lambda: ops.deconv5x5s2_scatter_f16(cur, wp, bp, m.in_channels, m.out_channels,
+                                                                  clamp01=clamp01, out=out))
+            continue
         if fewch:
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.deconv5x5s2_fewch_f16(cur, wp, bp, m.in_channels, m.out_channels,

@@ -497,6 +497,30 @@ def deconv5x5s2_fewch_f16(x_blk, w_packed, bias_padded, cin, cout, clamp01=False
     return y
 
 
+def pack_deconv_w_scatter_f16(w):
+    _dev(w)
+    cin, cout = w.shape[:2]
+    nbytes = _lib.load().licos_packed_deconv_w_scatter_bytes(cin, cout)
+    if nbytes == 0:
+        raise ValueError(f"licos_amd: scatter-form deconv supports 1..4 output channels, got {cout}")
+    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_pack_deconv_w_scatter_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
+               "pack_deconv_w_scatter_f16")
+    return packed
+
+
+def deconv5x5s2_scatter_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=None):
+    _dev(x_blk, w_packed, bias, out)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("deconv5x5s2_scatter_f16: input is not the blk16 fp16 layout of `cin` channels")
+    y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
+    rc = _lib.load().licos_deconv5x5s2_scatter_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(clamp01), b, cin, h, w, cout,
+                                                   _stream())
+    _lib.check(rc, "deconv5x5s2_scatter_f16")
+    return y
+
+
 def pack_conv3x3_w_f16(w):
     _dev(w)
     cout, cin = w.shape[:2]

@@ -84,6 +84,38 @@ def test_deconv_stage_exact_operands(cin, cout, h, w):
         assert rel_err(outf, ref.clamp(0, 1)) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 32, 32), (128, 1, 16, 16), (128, 3, 128, 128), (128, 2, 9, 40), (128, 4, 20, 36),
+                                           (192, 3, 8, 33), (192, 1, 5, 3), (128, 3, 1, 1)])
+def test_scatter_deconv_exact_operands(cin, cout, h, w):
+    """Scatter-form last stage: same operands as torch-CPU conv_transpose2d; fp32 MFMA sums, then 2^-20 fixed-point
+    accumulation of the <= 9 contributions per output pixel (|error| <= 9 * 2^-21), ragged tiles, every Cout."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cin, cout, 5, 5, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    ws = ops.pack_deconv_w_scatter_f16(wt.to(DEV))
+    bd = b.to(DEV)
+    out = ops.deconv5x5s2_scatter_f16(xb, ws, bd, cin, cout)
+    assert out.shape == ref.shape
+    assert float((out.cpu() - ref).abs().max()) < 9 * 2.0 ** -21 + 2e-5 * float(ref.abs().max())
+    outc = ops.deconv5x5s2_scatter_f16(xb, ws, bd, cin, cout, clamp01=True)
+    assert float((outc.cpu() - ref.clamp(0, 1)).abs().max()) < 9 * 2.0 ** -21 + 2e-5
+    # integer accumulation: the result does not depend on the order in which waves arrive
+    for _ in range(3):
+        assert torch.equal(ops.deconv5x5s2_scatter_f16(xb, ws, bd, cin, cout), out)
+
+
+def test_scatter_deconv_rejects_unsupported_shapes():
+    with pytest.raises(ValueError):
+        ops.pack_deconv_w_scatter_f16(torch.zeros(128, 5, 5, 5, device=DEV))
+    xb = torch.zeros(1, 4, 8, 8, 16, device=DEV, dtype=torch.float16)  # 64 input channels: not instantiated
+    ws = ops.pack_deconv_w_scatter_f16(torch.zeros(64, 3, 5, 5, device=DEV))
+    with pytest.raises(ValueError):
+        ops.deconv5x5s2_scatter_f16(xb, ws, torch.zeros(3, device=DEV), 64, 3)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("h,w", [(64, 64), (32, 32)])
 def test_fused_gdn_epilogue(inverse, h, w):

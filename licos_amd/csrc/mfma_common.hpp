@@ -81,19 +81,22 @@ __device__ inline void glds16(const void *gsrc, void *lds_wave_base) {
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// Double-buffered transposed conv (mfma_deconv.hip): a workgroup owns ONE output phase (py, px) of a TH x TW
-// input tile; a K-step is (cin chunk, kernel row of that phase): the TH input rows ty + dy with their
-// one-pixel x halo as granules [half][ty][x], plus that kernel row's 2 or 3 taps of weight fragments.
+// Transposed conv (mfma_deconv.hip): a workgroup owns ONE output phase (py, px) of a TH x TW input tile.  The
+// (TH+2) x (TW+2) input patch of a cin chunk is staged once, as granules [half][row][x], double-buffered by chunk;
+// a K-step is (cin chunk, kernel row of the phase): it reads the patch at row offset dy = 1 - iky and needs that
+// kernel row's 2 or 3 taps of weight fragments, double-buffered by step.
 template <int MT, int TH, int TW>
 struct DeconvStepGeom {
   static constexpr int RS = (TW == 16) ? 32 : round_up(TW + 2, 4);  // row stride; % 16 == 0 for 2-row pixel tiles
-  static constexpr int HALF = round_up(TH * RS, 32);
+  static constexpr int PH = TH + 2;                // input rows ty0-1 .. ty0+TH: every kernel row reads TH of them
+  static constexpr int HALF = PH * RS;
   static constexpr int PATCH_GRAN = 2 * HALF;
-  static constexpr int W_GRAN_MAX = 3 * MT * 64;
-  static constexpr int BUF_GRAN = PATCH_GRAN + W_GRAN_MAX;
+  static constexpr int PQ = (PATCH_GRAN + 63) / 64;  // wave-wide LDS-DMA pieces per patch
+  static constexpr int PATCH_PAD = PQ * 64;
+  static constexpr int W_GRAN_MAX = 3 * MT * 64;   // one kernel row of a phase: up to 3 taps
+  static constexpr int KLOOP_GRAN = 2 * PATCH_PAD + 2 * W_GRAN_MAX;
   static constexpr int GAMMA_GRAN = MT * MT * 2 * 64;
-  static constexpr int LDS_BYTES = 16 * ((2 * BUF_GRAN > GAMMA_GRAN) ? 2 * BUF_GRAN : GAMMA_GRAN);
-  static_assert(PATCH_GRAN % 64 == 0, "patch must be a whole number of wave-wide LDS-DMA pieces");
+  static constexpr int LDS_BYTES = 16 * ((KLOOP_GRAN > GAMMA_GRAN) ? KLOOP_GRAN : GAMMA_GRAN);
 };
 
 template <int TH, int TW>

@@ -3,9 +3,11 @@
 // out[2ty+py][2tx+px] = sum over ky = py (mod 2), kx = px (mod 2) of
 //                       in[ty + (py+2-ky)/2][tx + (px+2-kx)/2] * w[ky][kx]
 // so each of the 4 output phases is a stride-1 convolution with 3x3 / 3x2 / 2x3 / 2x2 taps.  A
-// workgroup computes one phase of a TH x TW input tile (all output channels); its K loop walks
-// (cin chunk) x (kernel row of the phase), each step LDS-DMA'd into the buffer the next step reads
-// while the MFMAs of the current one run (same scheme as mfma_conv.hip; 3 workgroups per CU).
+// workgroup computes one phase of a TH x TW input tile (all output channels).  The chunk's (TH+2) x (TW+2)
+// input patch is LDS-DMA'd once (every kernel row reads it at its own row offset) into the buffer the NEXT chunk's
+// steps will read; the K loop walks (cin chunk) x (kernel row of the phase), each step's weight row arriving in the
+// buffer the next step reads while the MFMAs of the current one run.  49 KB of LDS; the workgroup exits right
+// after its stores (stores and LDS-DMA share vmcnt on gfx950: a loop over phases would wait for them).
 #include "mfma_common.hpp"
 
 namespace licos {
@@ -15,7 +17,8 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
   using G = DeconvStepGeom<MT, TH, TW>;
   static_assert(TH * TW == 128 * NT, "tile must hold 4 waves x NT x 32 pixels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  half8 *s_buf = reinterpret_cast<half8 *>(smem);  // [2][BUF_GRAN]
+  half8 *s_pbuf = reinterpret_cast<half8 *>(smem);   // [2][PATCH_PAD]
+  half8 *s_wbuf = s_pbuf + 2 * G::PATCH_PAD;         // [2][W_GRAN_MAX]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
     const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W;
     oy[nt] = in ? (a.s1conv ? ty0 + ty : 2 * (ty0 + ty) + py) : -1;
     ox[nt] = a.s1conv ? tx0 + tx : 2 * (tx0 + tx) + px;
-    base[nt] = h * G::HALF + ty * G::RS + (tx + 1);
+    base[nt] = h * G::HALF + (ty + 1) * G::RS + (tx + 1);  // patch row 0 / column 0 = input row ty0-1 / column tx0-1
   }
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -49,49 +52,53 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
   const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
-  // per-lane description of this wave's patch pieces (fixed for the whole K loop)
-  constexpr int PQ = G::PATCH_GRAN / 64, NPP = (PQ + 3) / 4, NWP = (3 * MT + 3) / 4;
-  int p_off[NPP], p_row[NPP];
+  // per-lane source offset of this wave's patch pieces inside a chunk plane (-1: outside the image or padding);
+  // fixed for the whole K loop, because every kernel row reads the same patch
+  constexpr int NPP = (G::PQ + 3) / 4, NWP = (3 * MT + 3) / 4;
+  int p_off[NPP];
 #pragma unroll
   for (int i = 0; i < NPP; ++i) {
     const int d = (wave + 4 * i) * 64 + lane;
     const int hh = d / G::HALF, rem = d - hh * G::HALF;
     const int j = rem / G::RS, q = rem - j * G::RS;
-    const int ix = tx0 - 1 + q;
-    p_off[i] = (j * a.W + ix) * 2 + hh;
-    p_row[i] = (ix >= 0 && ix < a.W && j < TH && q < TW + 2) ? ty0 + j : -(1 << 20);
+    const int iy = ty0 - 1 + j, ix = tx0 - 1 + q;
+    const bool ok = d < G::PATCH_GRAN && q < TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    p_off[i] = ok ? (iy * a.W + ix) * 2 + hh : -1;
   }
-  const int wq = nkx * MT;  // weight pieces per step
-  auto stage = [&](int step, int buf) {
-    const int cc = step / nky, iky = step - nky * cc;
-    const int dy = 1 - iky;  // ky = py + 2*iky -> dy = (py + 2 - ky) / 2
-    const half8 *xrow = xb + (size_t)cc * plane * 2 + (ptrdiff_t)dy * a.W * 2;
-    const half8 *wsrc = a.wp + ((size_t)phase_tap0 * a.Cin16 + (size_t)cc * ntap + (size_t)iky * nkx) * MT * 64 + lane;
-    half8 *dst = s_buf + buf * G::BUF_GRAN;
+  auto dma_patch = [&](int cc, int buf, int q_lo, int q_hi) {
+    const half8 *xin = xb + (size_t)cc * plane * 2;
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
       const int q = wave + 4 * i;
-      if (q < PQ) {
-        const bool ok = (unsigned)(p_row[i] + dy) < (unsigned)a.H;
-        glds16(ok ? xrow + (ptrdiff_t)ty0 * a.W * 2 + p_off[i] : zero, dst + q * 64);
-      }
+      if (q >= q_lo && q < q_hi && q < G::PQ) glds16(p_off[i] >= 0 ? xin + p_off[i] : zero, s_pbuf + buf * G::PATCH_PAD + q * 64);
     }
+  };
+  const int wq = nkx * MT;  // weight pieces per step
+  auto dma_w = [&](int cc, int iky, int buf) {
+    const half8 *wsrc = a.wp + ((size_t)phase_tap0 * a.Cin16 + (size_t)cc * ntap + (size_t)iky * nkx) * MT * 64 + lane;
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
       const int q = wave + 4 * i;
-      if (q < wq) glds16(wsrc + q * 64, dst + G::PATCH_GRAN + q * 64);
+      if (q < wq) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN_MAX + q * 64);
     }
   };
+  const int per_step = (G::PQ + nky - 1) / nky;  // pieces of the next chunk's patch issued per step
 
-  const int S = a.Cin16 * nky;
-  stage(0, 0);
+  dma_patch(0, 0, 0, G::PQ);
+  dma_w(0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  for (int s = 0; s < S; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < S) stage(s + 1, cur ^ 1);
-    const half8 *s_patch = s_buf + cur * G::BUF_GRAN;
-    const half8 *s_w = s_patch + G::PATCH_GRAN;
+  int wcur = 0;
+  for (int cc = 0; cc < a.Cin16; ++cc) {
+    const int pcur = cc & 1;
+    const bool last_cc = cc + 1 == a.Cin16;
+    for (int iky = 0; iky < nky; ++iky) {
+      // prefetch: the next step's kernel row, and this step's share of the next chunk's patch
+      if (iky + 1 < nky) dma_w(cc, iky + 1, wcur ^ 1);
+      else if (!last_cc) dma_w(cc + 1, 0, wcur ^ 1);
+      if (!last_cc) dma_patch(cc + 1, pcur ^ 1, iky * per_step, (iky + 1) * per_step);
+      const half8 *s_patch = s_pbuf + pcur * G::PATCH_PAD + (1 - iky) * G::RS;  // ky = py + 2*iky -> dy = (py + 2 - ky) / 2 = 1 - iky
+      const half8 *s_w = s_wbuf + wcur * G::W_GRAN_MAX;
     // LDS reads run one item (one A fragment = NT MFMAs) ahead of their use, pinned by sched_group_barrier, so
     // the LDS latency sits under the previous item's MFMAs instead of in front of its own
     auto taps = [&](auto first_c, auto count_c) {  // taps [FIRST, FIRST + COUNT) of this kernel row
@@ -122,8 +129,12 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
     };
     taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
     if (nkx == 3) taps(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});  // wave-uniform: even-x phases
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+      // my DMA pieces have landed; after the barrier so have everyone's, and every wave is done reading the
+      // buffers the next step overwrites
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      wcur ^= 1;
+    }
   }
   const bf16x8 *gam = a.gamma;
   if (EPI == EPI_GDN || EPI == EPI_IGDN) {
@@ -142,7 +153,7 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
   // gamma fragments share the K-loop buffers' space; only (I)GDN epilogues need room for them
-  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)2 * G::BUF_GRAN * 16;
+  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::KLOOP_GRAN * 16;
   auto kern = deconv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -22,6 +22,15 @@ struct WordSink {
     if (wp > 0) { --wp; words[(size_t)wp * B + b] = w; }
     else overflow = true;
   }
+  // Branch-free form for the per-symbol renormalisation: the word is ALWAYS stored to the next free slot (a slot
+  // below wp is scratch until a real emission claims it, which overwrites whatever sits there) and the slot is
+  // claimed only when `emit` is set.
+  __device__ inline void put_if(bool emit, uint32_t w, bool live) {
+    const int slot = wp > 0 ? wp - 1 : 0;
+    if (live) words[(size_t)slot * B + b] = w;  // idle lanes shadow a real stream: they must not touch its slots
+    overflow = overflow || (emit && wp <= 0);
+    wp = emit ? slot : wp;
+  }
 };
 
 __device__ inline void put_bits4(uint64_t &x, WordSink &sink, uint32_t val) {
@@ -208,20 +217,23 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
       for (int k = 0; k < SYM_BATCH; ++k) {
         if (k >= nb) break;
         const int32_t value = sv[k] - off;
-        if (value < 0 || value >= max_value) {
-          const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
-          int nbyp = 0;
-          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-          if (live) {
-            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
-            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+        const bool escape = value < 0 || value >= max_value;
+        if (__any(escape)) {  // uniform and rare: some stream codes an out-of-range value
+          if (escape) {
+            const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
+            int nbyp = 0;
+            while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+            if (live) {
+              for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+              put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+            }
           }
         }
+        // straight-line renormalise + encode: x >= freq << 47 compares the high words (the low 47 bits of the bound are 0)
         const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
-        if (x >= ((uint64_t)freq << 47)) {
-          if (live) sink.put((uint32_t)x);
-          x >>= 32;
-        }
+        const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
+        sink.put_if(emit && live, (uint32_t)x, live);
+        x = emit ? (x >> 32) : x;
         const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
         x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
       }
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
 // no global memory operation: when ANY lane runs low the whole wave tops its rings up together (all loads
 // issued before the first is consumed: one memory round trip per refill, and refills are rare - a stream
 // averages well under one word per symbol), and decoded symbols leave through a 16-deep LDS buffer.
-constexpr int RING = 64, RING_LOW = 16, SYM_BUF = 16;
+constexpr int RING = 64, RING_LOW = 24, SYM_BUF = 16, LUT_BITS = 10;
 
 struct RingSource {
   const uint32_t *p;
@@ -267,6 +279,12 @@ struct RingSource {
   __device__ inline void refill_if_low() {
     if (__any(filled - rd <= RING_LOW)) top_up();
   }
+  // branch-free pair for the common renormalisation: peek() the next word early, advance(true) if it was used
+  __device__ inline uint32_t peek() const { return (rd < filled && rd < nw) ? ring[(rd & (RING - 1)) * 64] : 0u; }
+  __device__ inline void advance(bool used) {
+    over = over || (used && rd >= nw);
+    rd += used ? 1 : 0;
+  }
   __device__ inline uint32_t next() {
     if (rd >= nw) over = true;
     const uint32_t w = (rd < filled) ? ring[(rd & (RING - 1)) * 64] : 0u;  // rd >= filled only on malformed streams
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
   uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [RING][64] stream-word rings
   int32_t *s_out = reinterpret_cast<int32_t *>(s_ring + RING * 64);           // [SYM_BUF][64] decoded symbols
   uint32_t *s_cdf = reinterpret_cast<uint32_t *>(s_out + SYM_BUF * 64);       // [cdf_stride]
-  uint8_t *s_lut = reinterpret_cast<uint8_t *>(s_cdf) + (size_t)cdf_stride * 4;  // [256] when rows <= 256 entries
+  uint8_t *s_lut = reinterpret_cast<uint8_t *>(s_cdf) + (size_t)cdf_stride * 4;  // [1 << LUT_BITS] (uint16 when rows > 256 entries)
   uint16_t *s_lut16 = reinterpret_cast<uint16_t *>(s_lut);
   const bool wide = cdf_stride > 256;
   const int lane = threadIdx.x;
@@ -312,37 +330,56 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
     __syncthreads();
     for (int e = lane; e < len; e += 64) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
     __syncthreads();
-    // LUT over the top 8 bits of cf: largest s with cdf[s] <= k << 8
-    for (int k = lane; k < 256; k += 64) {
-      const uint32_t key = (uint32_t)k << 8;
+    // LUT over the top LUT_BITS bits of cf: largest s with cdf[s] <= k << (16 - LUT_BITS).  Each lane fills a run of
+    // consecutive keys: one binary search, then a forward walk.
+    constexpr int KPL = (1 << LUT_BITS) / 64;
+    {
+      const uint32_t key0 = (uint32_t)(lane * KPL) << (16 - LUT_BITS);
       int lo = 0, hi = len - 1;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (s_cdf[mid] <= key) lo = mid; else hi = mid;
+        if (s_cdf[mid] <= key0) lo = mid; else hi = mid;
       }
-      if (wide) s_lut16[k] = (uint16_t)lo; else s_lut[k] = (uint8_t)lo;
+      for (int k = 0; k < KPL; ++k) {
+        const uint32_t key = (uint32_t)(lane * KPL + k) << (16 - LUT_BITS);
+        while (lo + 1 < len - 1 && s_cdf[lo + 1] <= key) ++lo;
+        if (wide) s_lut16[lane * KPL + k] = (uint16_t)lo; else s_lut[lane * KPL + k] = (uint8_t)lo;
+      }
     }
     __syncthreads();
     for (int p = 0; p < plane; ++p) {
-      src.refill_if_low();
+      if ((p & 7) == 0) src.refill_if_low();  // a symbol takes at most one word off the ring outside the (rare) bypass path
+      // the next stream word is read before it is known to be needed: the LDS latency stays off the x -> x chain
+      const uint32_t w_next = src.peek();
       const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-      int s = wide ? (int)s_lut16[cf >> 8] : (int)s_lut[cf >> 8];
+      int s = wide ? (int)s_lut16[cf >> (16 - LUT_BITS)] : (int)s_lut[cf >> (16 - LUT_BITS)];
       uint32_t lo = s_cdf[s], hi = s_cdf[s + 1];
-      while (hi <= cf) { lo = hi; ++s; hi = s_cdf[s + 1]; }
+      while (__any(hi <= cf)) {  // uniform loop, per-lane select: the fine LUT makes a second pass rare
+        const bool adv = hi <= cf;
+        const uint32_t nxt = s_cdf[s + 1 + (adv ? 1 : 0)];
+        lo = adv ? hi : lo;
+        s += adv ? 1 : 0;
+        hi = adv ? nxt : hi;
+      }
       x = (uint64_t)(hi - lo) * (x >> 16) + cf - lo;
-      if (x < RANS_L) x = (x << 32) | src.next();
+      const bool need = x < RANS_L;
+      x = need ? ((x << 32) | w_next) : x;
+      src.advance(need);
       int32_t value = s;
-      if (value == max_value) {
-        uint32_t val = get_bits4p(x, src);
-        int nb = (int)val;
-        while (val == 15u && nb < 64) { val = get_bits4p(x, src); nb += (int)val; }
-        uint32_t raw = 0;
-        for (int j = 0; j < nb; ++j) {
-          const uint32_t nib = get_bits4p(x, src);
-          if (j < 8) raw |= nib << (j * 4);
+      if (__any(value == max_value)) {  // uniform and rare: some stream hit the escape symbol
+        if (value == max_value) {
+          uint32_t val = get_bits4p(x, src);
+          int nb = (int)val;
+          while (val == 15u && nb < 64) { val = get_bits4p(x, src); nb += (int)val; }
+          uint32_t raw = 0;
+          for (int j = 0; j < nb; ++j) {
+            const uint32_t nib = get_bits4p(x, src);
+            if (j < 8) raw |= nib << (j * 4);
+          }
+          value = (int32_t)(raw >> 1);
+          value = (raw & 1u) ? -value - 1 : value + max_value;
         }
-        value = (int32_t)(raw >> 1);
-        value = (raw & 1u) ? -value - 1 : value + max_value;
+        src.refill_if_low();  // the escape path may have drained several words
       }
       s_out[(p & (SYM_BUF - 1)) * 64 + lane] = value + off;
       if ((p & (SYM_BUF - 1)) == SYM_BUF - 1 || p == plane - 1) {  // uniform: flush the buffered symbols
@@ -600,7 +637,7 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + (size_t)cdf_stride * 4 + 512;
+  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + (size_t)cdf_stride * 4 + ((size_t)2 << LUT_BITS);
   if (!indexes && n % plane == 0 && dec_lds <= 64 * 1024) {
     hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,

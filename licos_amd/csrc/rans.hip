@@ -7,6 +7,7 @@
 // symbols in reverse (the encoder emits words back to front).  Words are staged in an
 // interleaved scratch [word][stream] so that lanes advancing in lock-step write coalesced.
 #include "common.hpp"
+#include <type_traits>
 
 namespace licos {
 
@@ -25,9 +26,9 @@ struct WordSink {
   // Branch-free form for the per-symbol renormalisation: the word is ALWAYS stored to the next free slot (a slot
   // below wp is scratch until a real emission claims it, which overwrites whatever sits there) and the slot is
   // claimed only when `emit` is set.
-  __device__ inline void put_if(bool emit, uint32_t w, bool live) {
+  __device__ inline void put_if(bool emit, uint32_t w) {
     const int slot = wp > 0 ? wp - 1 : 0;
-    if (live) words[(size_t)slot * B + b] = w;  // idle lanes shadow a real stream: they must not touch its slots
+    words[(size_t)slot * B + b] = w;
     overflow = overflow || (emit && wp <= 0);
     wp = emit ? slot : wp;
   }
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
     __syncthreads();
     for (int e = lane; e < len - 1; e += 64) s_tab[e] = table[(size_t)c * cdf_stride + e];
     __syncthreads();
+    if (!live) continue;  // idle lanes (last block only) sit out the coding loop: no per-symbol predication for them
     // symbols are fetched one batch ahead, so their load latency hides under the coding of the current batch
     int32_t sv_next[SYM_BATCH];
     auto fetch = [&](int p1, int32_t (&dst)[SYM_BATCH]) {
@@ -195,19 +197,15 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
       for (int k = 0; k < SYM_BATCH; ++k)
         dst[k] = (p1 - 1 - k >= 0) ? sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi] : 0;
     };
-    fetch(plane, sv_next);
-    for (int p1 = plane; p1 > 0; p1 -= SYM_BATCH) {
-      const int nb = p1 < SYM_BATCH ? p1 : SYM_BATCH;
-      int32_t sv[SYM_BATCH];
-#pragma unroll
-      for (int k = 0; k < SYM_BATCH; ++k) sv[k] = sv_next[k];
-      if (p1 - SYM_BATCH > 0) fetch(p1 - SYM_BATCH, sv_next);
+    // one batch of nb <= SYM_BATCH symbols (FULL: nb == SYM_BATCH, no per-symbol bound checks)
+    auto code_batch = [&](auto full_c, const int32_t (&sv)[SYM_BATCH], int nb) {
+      constexpr bool FULL = decltype(full_c)::value;
       // table records for the whole batch first: they do not depend on the coder state, so the LDS
       // latency stays off the serial x -> x chain below
       EncRec rec[SYM_BATCH];
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k) {
-        if (k < nb) {
+        if (FULL || k < nb) {
           int32_t value = sv[k] - off;
           value = (value < 0 || value >= max_value) ? max_value : value;
           rec[k] = s_tab[value];
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
       }
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k) {
-        if (k >= nb) break;
+        if (!FULL && k >= nb) break;
         const int32_t value = sv[k] - off;
         const bool escape = value < 0 || value >= max_value;
         if (__any(escape)) {  // uniform and rare: some stream codes an out-of-range value
@@ -223,21 +221,29 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
             const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
             int nbyp = 0;
             while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-            if (live) {
-              for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
-              put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
-            }
+            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
           }
         }
         // straight-line renormalise + encode: x >= freq << 47 compares the high words (the low 47 bits of the bound are 0)
         const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
         const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
-        sink.put_if(emit && live, (uint32_t)x, live);
+        sink.put_if(emit, (uint32_t)x);
         x = emit ? (x >> 32) : x;
         const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
         x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
       }
+    };
+    fetch(plane, sv_next);
+    int p1 = plane;
+    for (; p1 >= SYM_BATCH; p1 -= SYM_BATCH) {
+      int32_t sv[SYM_BATCH];
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k) sv[k] = sv_next[k];
+      if (p1 - SYM_BATCH > 0) fetch(p1 - SYM_BATCH, sv_next);
+      code_batch(std::true_type{}, sv, SYM_BATCH);
     }
+    if (p1 > 0) code_batch(std::false_type{}, sv_next, p1);
   }
   if (live) {
     sink.put((uint32_t)(x >> 32));

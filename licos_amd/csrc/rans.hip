@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
       }
     }
     __syncthreads();
+    if (!live) continue;  // idle lanes (last block only) sit out the decoding loop
     for (int p = 0; p < plane; ++p) {
       if ((p & 7) == 0) src.refill_if_low();  // a symbol takes at most one word off the ring outside the (rare) bypass path
       // the next stream word is read before it is known to be needed: the LDS latency stays off the x -> x chain
@@ -390,8 +391,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
       s_out[(p & (SYM_BUF - 1)) * 64 + lane] = value + off;
       if ((p & (SYM_BUF - 1)) == SYM_BUF - 1 || p == plane - 1) {  // uniform: flush the buffered symbols
         const int p0 = p & ~(SYM_BUF - 1);
-        if (live)
-          for (int k = 0; k <= p - p0; ++k) sp[(size_t)((size_t)c * plane + p0 + k) * ssi] = s_out[k * 64 + lane];
+        for (int k = 0; k <= p - p0; ++k) sp[(size_t)((size_t)c * plane + p0 + k) * ssi] = s_out[k * 64 + lane];
       }
     }
   }

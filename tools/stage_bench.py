@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import licos_amd
 from licos_amd import engine, synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 3  # input channels (3 RGB, 1 split band, 13 merged bands)
 dev = torch.device("cuda:0")
-net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(dev).eval().set_precision("fp16")
-x = synthetic.tiles(B, 3, 256, seed=1, device=dev)
+net = licos_amd.get_model("bmshj2018-factorized", False, C, 3).to(dev).eval().set_precision("fp16")
+x = synthetic.tiles(B, C, 256, seed=1, device=dev)
 with torch.no_grad():
     for it in range(3):
         engine.stage_events = {} if it == 2 else None

@@ -147,6 +147,10 @@ def main():
     stages = {}
     roof = roof_d2 = None
     if events:
+        for key, evs in events.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+            fl = stage_flops(*key[:5]) * key[5]
+            stages["%s_%d_%d_%dx%d_b%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
         # the two MFMA kernels the time goes to: g_a[2] (SURVEY.md section 8(d)'s target kernel, `roofline`) and
         # g_s[2], the largest single kernel of the step (`roofline_g_s2`); same algorithmic FLOPs per tile
         def roofline_of(kind, kernel_name, traffic_file):

@@ -183,6 +183,38 @@ def test_model_fp16_matches_oracle_rates(cin, kind):
     assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
 
 
+def test_bench_scale_batch_invariants():
+    """The bench workload (BASELINE configs[1]: q=3, 3-channel 256x256 tiles, fp16) at a batch far beyond what the
+    oracle can follow, checked through size-independent properties: decode(encode(x)) equals forward()'s
+    reconstruction bit for bit, the bytes do not depend on the pipeline chunking or on the run, every tile's string
+    equals the string the same tile gets when coded alone, and the byte count agrees with the likelihood bpp."""
+    from licos_amd import synthetic
+    torch.manual_seed(3)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(DEV).eval().set_precision("fp16")
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=0)
+    b = 1536
+    x = synthetic.tiles(b, 3, 256, seed=77, device=DEV)
+    with torch.no_grad():
+        net.chunk = 512
+        c1 = net.compress(x)
+        d1 = net.decompress(c1["strings"], c1["shape"])["x_hat"]
+        net.chunk = 1000  # ragged chunks
+        c2 = net.compress(x)
+        d2 = net.decompress([[bytes(s) for s in c2["strings"][0]]], c2["shape"])["x_hat"]
+        fwd = net(x)
+        pick = [0, 511, 512, 999, 1000, b - 1]  # chunk seams of both chunkings
+        alone = [net.compress(x[i:i + 1])["strings"][0][0] for i in pick]
+    s1, s2 = [bytes(s) for s in c1["strings"][0]], [bytes(s) for s in c2["strings"][0]]
+    assert len(s1) == b and s1 == s2
+    assert [s1[i] for i in pick] == [bytes(s) for s in alone]
+    assert torch.equal(d1, d2)
+    assert torch.equal(d1, fwd["x_hat"].clamp(0, 1))
+    bpp_bytes = 8.0 * sum(len(s) for s in s1) / (b * 256 * 256)
+    bpp_lik = licos_amd.metrics.compute_bpp(fwd)
+    assert abs(bpp_bytes - bpp_lik) < 0.02 * bpp_lik + 0.002  # coder overhead: a few bytes per stream
+
+
 def test_fp16_codec_accepts_plain_and_edited_string_lists():
     """compress() returns a list subclass that remembers its packed host buffer; decompress must give the
     same result for that object, for a plain list of the same bytes, and for a reordered plain list."""

@@ -215,6 +215,31 @@ def test_bench_scale_batch_invariants():
     assert abs(bpp_bytes - bpp_lik) < 0.02 * bpp_lik + 0.002  # coder overhead: a few bytes per stream
 
 
+@pytest.mark.parametrize("cin,h,w", [(3, 304, 464), (1, 16, 16), (13, 272, 336), (3, 1152, 1296)])
+def test_fp16_whole_images_of_any_multiple_of_16(cin, h, w):
+    """Images are not always 256x256 tiles: eval_script.py feeds whole granules (raw_utils.py:131: 1152x1296,
+    2304x2592 - multiples of 16, not of 64).  Every stage kernel must handle ragged tiles; the fp16 path is checked
+    against the fp32 path of the same module and against its own forward()."""
+    from licos_amd import synthetic
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 2).to(DEV).eval()
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=5)
+    size = -(-max(h, w) // 8) * 8
+    x = om.synthetic_tiles(1, cin, size, seed=h + w)[..., :h, :w].contiguous().to(DEV)
+    with torch.no_grad():
+        ref = net(x)  # fp32 path (parity-tested against the oracle)
+        net.set_precision("fp16")
+        out = net(x)
+        comp = net.compress(x)
+        dec = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+    assert tuple(out["x_hat"].shape) == (1, cin, h, w) and tuple(comp["shape"]) == (h // 16, w // 16)
+    assert torch.equal(dec, out["x_hat"].clamp(0, 1))
+    psnr16 = licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x)
+    psnr32 = licos_amd.metrics.compute_psnr(ref["x_hat"].clamp(0, 1), x)
+    bpp16, bpp32 = licos_amd.metrics.compute_bpp(out), licos_amd.metrics.compute_bpp(ref)
+    assert abs(psnr16 - psnr32) < 0.1 and abs(bpp16 - bpp32) < 0.01 * bpp32 + 1e-3, (psnr16, psnr32, bpp16, bpp32)
+
+
 def test_fp16_codec_accepts_plain_and_edited_string_lists():
     """compress() returns a list subclass that remembers its packed host buffer; decompress must give the
     same result for that object, for a plain list of the same bytes, and for a reordered plain list."""

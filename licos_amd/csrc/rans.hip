@@ -445,6 +445,7 @@ __global__ __launch_bounds__(64) void rans_encode_indexed_kernel(const int32_t *
     for (int e = lane; e < s_len[r] - 1; e += 64) s_tab[base + e] = table[(size_t)r * cdf_stride + e];
   }
   __syncthreads();
+  if (!live) return;  // the tables are staged: idle lanes (last block only) have nothing left to do
   WordSink sink{words, B, b, cap_words, false};
   uint64_t x = RANS_L;
   const int32_t *sp = symbols + (size_t)b * ssb;
@@ -458,9 +459,12 @@ __global__ __launch_bounds__(64) void rans_encode_indexed_kernel(const int32_t *
       iv_next[k] = (i >= 0) ? ip[(size_t)i * ssi] : 0;
     }
   };
-  fetch(n);
-  for (int i1 = n; i1 > 0; i1 -= SYM_BATCH) {
-    const int nb = i1 < SYM_BATCH ? i1 : SYM_BATCH;
+  int fetch_from = 0;
+  auto fetch_next = [&]() { fetch(fetch_from); };
+  // one batch of nb <= SYM_BATCH symbols (FULL: nb == SYM_BATCH, no per-symbol bound checks); same straight-line
+  // step as the plane kernel
+  auto code_batch = [&](auto full_c, int nb, bool more) {
+    constexpr bool FULL = decltype(full_c)::value;
     int32_t sv[SYM_BATCH], mx[SYM_BATCH];
     EncRec rec[SYM_BATCH];
 #pragma unroll
@@ -472,35 +476,40 @@ __global__ __launch_bounds__(64) void rans_encode_indexed_kernel(const int32_t *
       const int base = s_base[c];
       rec[k] = (base >= 0) ? s_tab[base + v] : table[(size_t)c * cdf_stride + v];
     }
-    if (i1 - SYM_BATCH > 0) fetch(i1 - SYM_BATCH);
+    if (more) fetch_next();
 #pragma unroll
     for (int k = 0; k < SYM_BATCH; ++k) {
-      if (k >= nb) break;
+      if (!FULL && k >= nb) break;
       const int32_t value = sv[k];
-      if (value < 0 || value >= mx[k]) {
-        const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - mx[k]));
-        int nbyp = 0;
-        while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-        if (live) {
+      const bool escape = value < 0 || value >= mx[k];
+      if (__any(escape)) {  // uniform and rare
+        if (escape) {
+          const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - mx[k]));
+          int nbyp = 0;
+          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
           for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
           put_bits4(x, sink, (uint32_t)nbyp);
         }
       }
       const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
-      if (x >= ((uint64_t)freq << 47)) {
-        if (live) sink.put((uint32_t)x);
-        x >>= 32;
-      }
+      const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
+      sink.put_if(emit, (uint32_t)x);
+      x = emit ? (x >> 32) : x;
       const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
       x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
     }
+  };
+  fetch(n);
+  int i1 = n;
+  for (; i1 >= SYM_BATCH; i1 -= SYM_BATCH) {
+    fetch_from = i1 - SYM_BATCH;
+    code_batch(std::true_type{}, SYM_BATCH, i1 - SYM_BATCH > 0);
   }
-  if (live) {
-    sink.put((uint32_t)(x >> 32));
-    sink.put((uint32_t)x);
-    nwords[b] = cap_words - sink.wp;
-    if (sink.overflow) atomicOr(status, 1);
-  }
+  if (i1 > 0) code_batch(std::false_type{}, i1, false);
+  sink.put((uint32_t)(x >> 32));
+  sink.put((uint32_t)x);
+  nwords[b] = cap_words - sink.wp;
+  if (sink.overflow) atomicOr(status, 1);
 }
 
 __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *__restrict__ in,

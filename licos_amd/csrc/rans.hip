@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
 // as fit IDX_CAP entries, decided by the kernel itself from cdf_len), the long ones stay in global memory.
 // Symbols and row indexes are fetched a batch ahead; the decoder shares the plane kernel's LDS word ring and
 // buffered symbol stores.
-constexpr int IDX_CAP = 2560, IDX_MAX_ROWS = 256;
+constexpr int IDX_CAP = 2560, IDX_MAX_ROWS = 256, IDX_LUT_ROWS = 64, IDX_LUT_BITS = 6, IDX_LUT_N = 1 << IDX_LUT_BITS;
 
 struct IdxTables {
   int *s_len, *s_off, *s_base;  // [rows] cdf length, symbol offset, first staged entry (or -1)
@@ -523,6 +523,11 @@ __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *
   __shared__ uint32_t s_cdf[IDX_CAP];
   __shared__ uint32_t s_ring[RING * 64];
   __shared__ int32_t s_out[SYM_BUF * 64];
+  // per-row search LUT over the top IDX_LUT_BITS bits of cf: s_lut[r][k] = largest s with row[s] <= k << (16 - bits),
+  // plus one closing entry len - 2; the symbol of cf then lies in [s_lut[k], s_lut[k+1] + 1) and the binary search
+  // below needs a step or two instead of log2(len) - with 64 streams in lock-step every saved step is saved 64 times
+  __shared__ uint16_t s_lut[IDX_LUT_ROWS * (IDX_LUT_N + 1)];
+  const bool use_lut = rows <= IDX_LUT_ROWS;
   const int lane = threadIdx.x;
   const int b_raw = blockIdx.x * 64 + lane;
   const bool live = b_raw < B;
@@ -534,6 +539,26 @@ __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *
     for (int e = lane; e < s_len[r]; e += 64) s_cdf[base + e] = (uint32_t)cdf[(size_t)r * cdf_stride + e];
   }
   __syncthreads();
+  if (use_lut) {
+    for (int e = lane; e < rows * (IDX_LUT_N + 1); e += 64) {
+      const int r = e / (IDX_LUT_N + 1), k = e - r * (IDX_LUT_N + 1);
+      const int len = s_len[r];
+      int lo = len - 2;
+      if (k < IDX_LUT_N) {
+        const uint32_t key = (uint32_t)k << (16 - IDX_LUT_BITS);
+        const int base = s_base[r];
+        lo = 0;
+        int hi = len - 1;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          const uint32_t v = base >= 0 ? s_cdf[base + mid] : (uint32_t)cdf[(size_t)r * cdf_stride + mid];
+          if (v <= key) lo = mid; else hi = mid;
+        }
+      }
+      s_lut[e] = (uint16_t)lo;
+    }
+    __syncthreads();
+  }
   RingSource src;
   src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane);
   uint64_t x = (uint64_t)src.next();
@@ -562,6 +587,11 @@ __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *
       const int base = s_base[c];
       const uint32_t cf = (uint32_t)(x & 0xFFFFu);
       int lo = 0, hi = len - 1;  // row[lo] <= cf < row[hi]
+      if (use_lut) {
+        const uint16_t *lr = s_lut + c * (IDX_LUT_N + 1) + (cf >> (16 - IDX_LUT_BITS));
+        lo = lr[0];
+        hi = lr[1] + 1;
+      }
       uint32_t vlo, vhi;
       if (base >= 0) {
         const uint32_t *row = s_cdf + base;

@@ -189,6 +189,7 @@ int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStrea
   if (MT == 4 && epi == EPI_RELU) return dispatch_tile<4, EPI_RELU>(a, width, s);
   if (MT == 6 && epi == EPI_RELU) return dispatch_tile<6, EPI_RELU>(a, width, s);
   if (MT == 10 && epi == EPI_NONE) return dispatch_tile<10, EPI_NONE>(a, width, s);
+  if (MT == 10 && epi == EPI_RELU) return dispatch_tile<10, EPI_RELU>(a, width, s);  // h_s[4] of the q6-8 hyperprior (N -> M = 320, ReLU)
   return fail(LICOS_EINVAL, "mfma deconv: %d output channels with epilogue %d not instantiated", 32 * MT, epi);
 }
 

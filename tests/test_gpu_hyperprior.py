@@ -105,3 +105,23 @@ def test_hyperprior_fp16_config5_size():
     psnr_ref = om.compute_psnr(ref["x_hat"].clamp(0, 1), x)
     print(f"hyperprior fp16 13x512x512: bpp {bpp:.4f} vs {bpp_ref:.4f}, PSNR {psnr:.3f} vs {psnr_ref:.3f}")
     assert abs(bpp - bpp_ref) < 0.01 * bpp_ref and abs(psnr - psnr_ref) < 0.1
+
+
+@pytest.mark.parametrize("model", ["bmshj2018-factorized", "bmshj2018-factorized-relu", "bmshj2018-hyperprior"])
+@pytest.mark.parametrize("quality", [2, 7])
+def test_every_zoo_model_and_width_round_trips(model, quality):
+    """Both channel tiers (q1-5: N=128, M=192; q6-8: N=192, M=320) of every model LICOS's get_model admits
+    (model_utils.py:20-24), both precisions: compress -> decompress reproduces forward()'s reconstruction."""
+    from licos_amd import synthetic
+    net = licos_amd.get_model(model, False, 3, quality).to(DEV).eval()
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=quality)
+    x = torch.round(torch.rand(2, 3, 128, 192, device=DEV) * 255) / 255
+    for prec in ("fp32", "fp16"):
+        net.set_precision(prec)
+        with torch.no_grad():
+            out = net(x)
+            comp = net.compress(x)
+            dec = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+        assert bool(torch.isfinite(out["x_hat"]).all())
+        assert float((dec - out["x_hat"].clamp(0, 1)).abs().max()) < (1e-5 if prec == "fp32" else 1e-6), (model, quality, prec)

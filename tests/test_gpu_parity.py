@@ -370,3 +370,50 @@ def test_granule_tiling_and_dn_conversion():
         coded = tiling.compress_image(net, x)
         rec = tiling.decompress_image(net, coded)["x_hat"]
     assert len(coded["strings"][0]) == 6 and tuple(rec.shape) == tuple(x.shape)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_corrupted_strings_never_fault(precision):
+    """Bit flips, truncation, zeros and random bytes in a stream: the decoders either raise ValueError (stream ran out)
+    or return a tensor of the right shape - they never read outside a string - and good strings keep decoding."""
+    import random
+    from licos_amd import synthetic
+    rnd = random.Random(5)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 2).to(DEV).eval()
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=3)
+    net.set_precision(precision)
+    x = torch.round(torch.rand(5, 3, 128, 128, device=DEV) * 255) / 255
+    with torch.no_grad():
+        comp = net.compress(x)
+        good = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+    base = [bytes(s) for s in comp["strings"][0]]
+    outcomes = set()
+    for trial in range(24):
+        strs = list(base)
+        si = rnd.randrange(5)
+        s = bytearray(strs[si])
+        kind = ("flip", "trunc", "zero", "garbage", "short")[trial % 5]
+        if kind == "flip":
+            for _ in range(rnd.randint(1, 20)):
+                s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        elif kind == "trunc":
+            s = s[: max(8, (len(s) // 2) // 4 * 4)]
+        elif kind == "zero":
+            s = bytearray(len(s))
+        elif kind == "garbage":
+            s = bytearray(rnd.getrandbits(8) for _ in range(len(s)))
+        else:
+            s = s[:8]
+        strs[si] = bytes(s)
+        try:
+            with torch.no_grad():
+                out = net.decompress([strs], comp["shape"])["x_hat"]
+            torch.cuda.synchronize()
+            assert out.shape == x.shape
+            outcomes.add("decoded")
+        except ValueError:
+            outcomes.add("rejected")
+    assert outcomes <= {"decoded", "rejected"} and "rejected" in outcomes
+    with torch.no_grad():
+        assert torch.equal(net.decompress([base], comp["shape"])["x_hat"], good)

@@ -423,15 +423,35 @@ class GaussianConditional(nn.Module):
             training = self.training
         inputs = inputs.contiguous()
         zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
-        if training:
-            if noise is None:
-                noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)
-            outputs = ops.eb_quantize(inputs, zeros, "noise", noise=noise.contiguous())
-        else:
-            outputs = ops.eb_quantize(inputs, zeros, "dequantize")
         bound = self.likelihood_lower_bound.bound_value if self.use_likelihood_bound else 0.0
-        lik = ops.gc_likelihood(outputs, scales.contiguous(), self.lower_bound_scale.bound_value, bound, sum_log2)
-        return outputs, lik
+        if training and noise is None:
+            noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)
+
+        def hip(xx, ss):
+            if training:
+                outs = ops.eb_quantize(xx.contiguous(), zeros, "noise", noise=noise.contiguous())
+            else:
+                outs = ops.eb_quantize(xx.contiguous(), zeros, "dequantize")
+            return outs, ops.gc_likelihood(outs, ss.contiguous(), self.lower_bound_scale.bound_value, bound, sum_log2)
+
+        if torch.is_grad_enabled() and (inputs.requires_grad or scales.requires_grad):
+            from . import autograd
+            # HIP forward; gradients with respect to the latents AND the predicted scales by re-evaluation of
+            # CompressAI's definition (GaussianConditional._likelihood, LowerBound's gradient rule) in torch ops
+            def ref(xx, ss):
+                outs = xx + noise if training else torch.round(xx)
+                sc = autograd.lower_bound_ref(ss, self.lower_bound_scale.bound)
+                v = torch.abs(outs)
+                const = -(2 ** -0.5)
+                upper = 0.5 * torch.erfc(const * ((0.5 - v) / sc))
+                lower = 0.5 * torch.erfc(const * ((-0.5 - v) / sc))
+                lik = upper - lower
+                if self.use_likelihood_bound:
+                    lik = autograd.lower_bound_ref(lik, self.likelihood_lower_bound.bound)
+                return outs, lik
+
+            return autograd.HipForward.apply(hip, ref, inputs, scales)
+        return hip(inputs, scales)
 
     def build_indexes_interleaved(self, scales):
         """Table row per element in the coder's [position][stream] layout."""

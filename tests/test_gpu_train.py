@@ -33,7 +33,7 @@ def test_train_step_matches_cpu_autograd():
     ref_out = om.forward(x, ref_sd, training=True, noise=noise)
     ref_res = om.rate_distortion_loss(ref_out, x, 1e-2)
     ref_res["loss"].backward()
-    assert abs(float(res["loss"]) - float(ref_res["loss"])) < 1e-4 * abs(float(ref_res["loss"]))
+    assert abs(float(res["loss"].detach()) - float(ref_res["loss"].detach())) < 1e-4 * abs(float(ref_res["loss"].detach()))
     checked = 0
     for name, p in net.named_parameters():
         rg = ref_sd[name].grad
@@ -148,3 +148,40 @@ def test_fused_adam_and_clip_match_torch():
     optimizers.clip_grad_norm_(dev_p, 1.0)
     tot = sum(float((q.grad.double() ** 2).sum()) for q in dev_p) ** 0.5
     assert abs(tot - 1.0) < 1e-3
+
+
+def test_gaussian_conditional_gradients_match_cpu_autograd():
+    """Scale-hyperprior training: the y likelihood must carry gradients to the latents AND to the predicted scales
+    (h_s), with CompressAI's LowerBound gradient rule on the scale and likelihood bounds."""
+    g = torch.Generator().manual_seed(4)
+    y = (3.0 * torch.randn(2, 8, 6, 5, generator=g)).requires_grad_(True)
+    scales = (torch.rand(2, 8, 6, 5, generator=g) * 2.0 + 0.02).requires_grad_(True)  # some below the 0.11 bound
+    noise = torch.rand(2, 8, 6, 5, generator=g) - 0.5
+    gc = licos_amd.GaussianConditional(None).to(DEV).train()
+    yd, sd_ = y.detach().to(DEV).requires_grad_(True), scales.detach().to(DEV).requires_grad_(True)
+    out, lik = gc(yd, sd_, noise=noise.to(DEV))
+    (torch.log2(lik).sum() + 0.1 * out.sum()).backward()
+
+    from licos_amd import autograd
+    s = autograd.lower_bound_ref(scales, torch.tensor([0.11]))
+    v = torch.abs(y + noise)
+    c = -(2 ** -0.5)
+    ref = 0.5 * torch.erfc(c * ((0.5 - v) / s)) - 0.5 * torch.erfc(c * ((-0.5 - v) / s))
+    ref = autograd.lower_bound_ref(ref, torch.tensor([1e-9]))
+    (torch.log2(ref).sum() + 0.1 * (y + noise).sum()).backward()
+    assert torch.allclose(lik.detach().cpu(), ref.detach(), rtol=2e-5, atol=1e-9)
+    for a, b in ((yd.grad.cpu(), y.grad), (sd_.grad.cpu(), scales.grad)):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+
+
+def test_hyperprior_training_reaches_every_parameter():
+    net = licos_amd.get_model("bmshj2018-hyperprior", False, 3, 1).to(DEV).train()
+    x = torch.rand(2, 3, 128, 128, device=DEV)
+    out = net(x)
+    res = licos_amd.RateDistortionLoss(lmbda=1e-2)(out, x)
+    res["loss"].backward()
+    missing = [n for n, p in net.named_parameters() if p.requires_grad and p.grad is None and not n.endswith("quantiles")]
+    assert missing == [], missing
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+    for name in ("g_a.0.weight", "h_a.0.weight", "h_s.0.weight", "g_s.0.weight"):
+        assert float(dict(net.named_parameters())[name].grad.abs().max()) > 0.0, name

@@ -33,11 +33,15 @@ class TransformSequential(nn.Sequential):
 
     def forward(self, x):
         if self.precision == "fp16" and not self.fp32_only:
-            if autograd.needs_grad(x, *self.parameters()):
+            # the fp16 MFMA path is inference-only.  In train() mode a needed gradient is an error (silently returning
+            # a detached tensor would train nothing); in eval() mode - evaluation loops, compress()/decompress()
+            # called without torch.no_grad(), as CompressAI allows - it simply runs without a graph
+            if self.training and autograd.needs_grad(x, *self.parameters()):
                 raise NotImplementedError("licos_amd: training (autograd) runs on precision='fp32'; the fp16 MFMA "
-                                          "path is inference-only (wrap evaluation in torch.no_grad())")
+                                          "path is inference-only (use net.eval() / torch.no_grad() to evaluate)")
             from .engine import run_chain_fp16
-            return run_chain_fp16(self, x)
+            with torch.no_grad():
+                return run_chain_fp16(self, x)
         return run_chain_fp32(self, x)
 
 

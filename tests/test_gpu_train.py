@@ -57,8 +57,15 @@ def test_train_step_matches_cpu_autograd():
     net.set_precision("fp16")
     with pytest.raises(NotImplementedError):
         net(x.to(DEV))
-    with torch.no_grad():
-        net.eval()(x.to(DEV))
+    # ... but only in train() mode: in eval() mode, forward / compress / decompress run without a graph even when the
+    # caller forgot torch.no_grad() (CompressAI's compress() works that way too)
+    net.eval()
+    net.update(force=True)
+    out = net(x.to(DEV))
+    assert out["x_hat"].grad_fn is None
+    comp = net.compress(x.to(DEV))
+    dec = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+    assert torch.equal(dec, out["x_hat"].clamp(0, 1))
 
 
 @pytest.mark.parametrize("cin,cout,h,w,k,s", [(3, 16, 20, 28, 5, 2), (16, 24, 17, 33, 5, 2), (8, 8, 9, 9, 3, 1),

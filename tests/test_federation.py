@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, losses, best, out):
+def _worker(rank, world, port, losses, best, out, save_path=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,7 +31,8 @@ def _worker(rank, world, port, losses, best, out):
         sd = om.perturb_state(om.make_factorized_state(3, 1, seed=rank), seed=rank)
         net.load_state_dict(sd)
         before = {k: v.clone() for k, v in net.state_dict().items()}
-        fs = federation.update_central_model(rank, "cpu", 0, net, losses[rank], best[rank], 0.0)
+        cfg = None if save_path is None else {"save_path": save_path, "save_checkpoints_over_time": True}
+        fs = federation.update_central_model(rank, "cpu", 5, net, losses[rank], best[rank], 12.5, cfg)
         assert federation.clock_sync(1) == world
         # parameters are views of the bucket: the module sees the averaged values without a load
         after = {k: v.clone() for k, v in net.state_dict().items()}
@@ -44,7 +45,8 @@ def test_weighted_allreduce_matches_sequential_blend(tmp_path):
     world = 2
     losses, best = [0.9, 0.6], [0.7, 0.6]
     out = str(tmp_path / "r{rank}.pt")
-    mp.spawn(_worker, args=(world, _free_port(), losses, best, out), nprocs=world, join=True)
+    save_path = str(tmp_path / "central_model")
+    mp.spawn(_worker, args=(world, _free_port(), losses, best, out, save_path), nprocs=world, join=True)
     res = [torch.load(out.format(rank=r)) for r in range(world)]
     float_keys = [k for k, v in res[0]["before"].items() if v.dtype == torch.float32]
     ref = om.sequential_federation([{k: r["before"][k] for k in float_keys} for r in res], losses, best)
@@ -55,6 +57,17 @@ def test_weighted_allreduce_matches_sequential_blend(tmp_path):
         for k, v in r["before"].items():
             if v.dtype != torch.float32:
                 assert torch.equal(r["after"][k], v)  # integer tables untouched
+
+
+    # the averaged model is left on disk as the reference's "central model" (federation_utils.py:58-83), with its dict
+    # layout, plus per-rank over-time checkpoints (licos/utils.py:82-111)
+    central = torch.load(save_path + ".pth.tar", weights_only=False)
+    assert set(central) == {"batch_idx", "state_dict", "loss", "local_time"} and central["batch_idx"] == 5
+    for k in float_keys:
+        assert torch.allclose(central["state_dict"][k], ref[k], rtol=1e-5, atol=1e-7), k
+    for r in range(world):
+        assert os.path.exists(os.path.join(save_path, "central_model_time_checkpoints",
+                                           "central_model_rank_%d_sim_time=12.5.pth.tar" % r))
 
 
 def test_reference_coefficients_closed_form():

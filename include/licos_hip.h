@@ -254,6 +254,9 @@ int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, 
  * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
  * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the
  * strided halo patch into a one-pixel halo.  H, W (even) are the ORIGINAL image size. */
+/* As licos_nchw_f32_to_blk16, plus the residual y_lo = fp16((x - float(y_hi)) * 2^lo_shift). */
+int licos_nchw_f32_split_blk16(const float *x, void *y_hi_blk16, void *y_lo_blk16, int B, int C, int H, int W, int abs_input,
+                               int lo_shift, void *stream);
 int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
 int licos_pack_conv_w_s2d_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, const float *bias,
@@ -279,6 +282,14 @@ int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scat
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2
 #define LICOS_EPI_RELU 3 /* bmshj2018-factorized-relu: ReLU in place of (I)GDN */
+/* OR-ed into `epilogue` (NCHW fp32 output, epilogue NONE or RELU): y_nchw += result, then ReLU / clamp on the sum.
+ * Three passes over fp16-split operands (licos_nchw_f32_split_blk16: x = hi + 2^-k lo; weights split the same way on
+ * the host side): hi*hi (+bias), hi*lo, lo*hi with fp32 accumulation reproduce an fp32 convolution to ~1e-6 - the fp32
+ * parity path of torch's conv2d / conv_transpose2d (licos/train.py:190, eval_utils.py:200) at MFMA speed. */
+#define LICOS_EPI_ACCUMULATE 0x100
+/* with LICOS_EPI_ACCUMULATE: y_nchw += 2^-k * result, k = 0..63 - undoes the 2^k by which a residual operand was scaled
+ * up before its conversion to fp16 (licos_nchw_f32_split_blk16's lo_shift, the weight residual likewise) */
+#define LICOS_EPI_SCALE_DOWN(k) (((k) & 63) << 12)
 /* x: blk16 [B][Cin16/16][H][W][16]; out: blk16 fp16 (y_blk16) or NCHW fp32 (y_nchw), exactly one non-NULL.
  * Cout_real <= Cout_packed: channels beyond Cout_real are not stored.  H, W are the INPUT size. */
 int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,

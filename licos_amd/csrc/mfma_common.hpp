@@ -118,6 +118,8 @@ struct MfmaArgs {
   int Ho, Wo, Cout;       // output geometry; Cout = real channel count (<= 32*MT)
   int tiles_x, tiles_y;
   int clamp01;
+  int accum;              // NCHW fp32 output: y += out_scale * result (then ReLU / clamp), for the split-operand fp32 passes
+  float out_scale;        // 2^-k of LICOS_EPI_SCALE_DOWN(k); 1 otherwise
   int s1conv;             // deconv kernel used as a 3x3 stride-1 conv (space-to-depth first stage): one 'phase', no upsampling
   const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
 };
@@ -231,9 +233,13 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
           for (int e = 0; e < 4; ++e) {
             float v = acc[it][nt][4 * g + e];
             if (EPI == EPI_GDN || EPI == EPI_IGDN) v *= scale[nt][4 * g + e];
-            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-            if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-            if (live && c0 + e < a.Cout) a.y_nchw[(((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt]] = v;
+            if (live && c0 + e < a.Cout) {
+              float *dst = a.y_nchw + (((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt];
+              if (a.accum) v = fmaf(v, a.out_scale, *dst);
+              if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+              if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+              *dst = v;
+            }
           }
         }
       }

@@ -161,14 +161,16 @@ __global__ void pack_conv3x3_w_kernel(const float *__restrict__ w, int Cin, int 
   }
 }
 
-__global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int C16, long HW,
-                                     long total, int abs_input) {
+// y = fp16(x); with y_res also the residual fp16((x - float(y)) * 2^shift): x = y + y_res * 2^-shift to ~22 bits, the operand split of the
+// "fp32 through three fp16 MFMA passes" path (hi*hi + hi*lo + lo*hi, fp32 accumulation)
+__global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, _Float16 *__restrict__ y_res,
+                                     int C, int C16, long HW, long total, int abs_input, float res_scale) {
   // one thread per (b, chunk, pixel): writes 16 halfs (32 B)
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long p = e % HW;
     const int cc = (int)((e / HW) % C16);
     const long b = e / (HW * C16);
-    half8 lo, hi;
+    half8 lo, hi, rlo, rhi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c0 = cc * 16 + j, c1 = c0 + 8;
@@ -177,10 +179,17 @@ __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__re
       if (abs_input) { v0 = fabsf(v0); v1 = fabsf(v1); }
       lo[j] = (_Float16)v0;
       hi[j] = (_Float16)v1;
+      rlo[j] = (_Float16)((v0 - (float)lo[j]) * res_scale);  // scaled up so the residual keeps all 11 bits (no fp16 subnormals)
+      rhi[j] = (_Float16)((v1 - (float)hi[j]) * res_scale);
     }
     half8 *dst = reinterpret_cast<half8 *>(y + (size_t)e * 16);
     dst[0] = lo;
     dst[1] = hi;
+    if (y_res) {
+      half8 *rd = reinterpret_cast<half8 *>(y_res + (size_t)e * 16);
+      rd[0] = rlo;
+      rd[1] = rhi;
+    }
   }
 }
 
@@ -296,14 +305,26 @@ int licos_pack_conv3x3_w_f16(const float *w, int Cin, int Cout, void *packed, vo
   return LICOS_OK;
 }
 
-int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, int abs_input, void *stream) {
-  LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_blk16: bad arguments");
+static int nchw_to_blk16_launch(const float *x, void *y_blk16, void *y_res, int B, int C, int H, int W, int abs_input,
+                                int res_shift, void *stream, const char *who) {
+  LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0, "%s: bad arguments", who);
   const int C16 = (C + 15) / 16;
   const long HW = (long)H * W, total = (long)B * C16 * HW;
   hipLaunchKernelGGL(nchw_to_blk16_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,
-                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), C, C16, HW, total, abs_input);
+                     as_stream(stream), x, static_cast<_Float16 *>(y_blk16), static_cast<_Float16 *>(y_res), C, C16, HW, total,
+                     abs_input, ldexpf(1.f, res_shift));
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
+}
+
+int licos_nchw_f32_to_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, int abs_input, void *stream) {
+  return nchw_to_blk16_launch(x, y_blk16, nullptr, B, C, H, W, abs_input, 0, stream, "nchw_f32_to_blk16");
+}
+
+int licos_nchw_f32_split_blk16(const float *x, void *y_hi_blk16, void *y_lo_blk16, int B, int C, int H, int W, int abs_input,
+                               int lo_shift, void *stream) {
+  LICOS_REQUIRE(y_lo_blk16 && lo_shift >= 0 && lo_shift <= 24, "nchw_f32_split_blk16: bad residual buffer / shift");
+  return nchw_to_blk16_launch(x, y_hi_blk16, y_lo_blk16, B, C, H, W, abs_input, lo_shift, stream, "nchw_f32_split_blk16");
 }
 
 int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream) {
@@ -335,7 +356,12 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   const int MT = mt_for(Cout);
   LICOS_REQUIRE(MT > 0 && Cout > 0, "%s: Cout=%d unsupported (max 320)", who, Cout);
   LICOS_REQUIRE((epi != EPI_GDN && epi != EPI_IGDN) || gdn, "%s: (I)GDN epilogue needs packed gamma/beta", who);
+  const int accum = (epi & LICOS_EPI_ACCUMULATE) ? 1 : 0;
+  const int down = (epi >> 12) & 63;  // LICOS_EPI_SCALE_DOWN(k)
+  epi &= 0xff;
+  LICOS_REQUIRE(down == 0 || accum, "%s: LICOS_EPI_SCALE_DOWN goes with LICOS_EPI_ACCUMULATE", who);
   LICOS_REQUIRE(epi >= 0 && epi <= 3, "%s: bad epilogue %d", who, epi);
+  LICOS_REQUIRE(!accum || (y_nchw && epi != EPI_GDN && epi != EPI_IGDN), "%s: LICOS_EPI_ACCUMULATE needs an NCHW fp32 output and no (I)GDN", who);
   LICOS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)bias & 15) == 0, "%s: buffers must be 16-byte aligned", who);
   a.x = static_cast<const _Float16 *>(x);
   a.wp = static_cast<const half8 *>(wp);
@@ -350,6 +376,8 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   a.W = W;
   a.Cout = Cout;
   a.clamp01 = 0;
+  a.accum = accum;
+  a.out_scale = ldexpf(1.f, -down);
   a.s1conv = 0;
   a.zero16 = zero_page();
   LICOS_REQUIRE(a.zero16 != nullptr, "%s: could not allocate the zero page", who);
@@ -366,7 +394,7 @@ int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *
   if (rc != LICOS_OK) return rc;
   a.Ho = (H - 1) / 2 + 1;
   a.Wo = (W - 1) / 2 + 1;
-  return mfma_dispatch_conv(a, MT, epilogue, a.Wo, as_stream(stream));
+  return mfma_dispatch_conv(a, MT, epilogue & 0xff, a.Wo, as_stream(stream));
 }
 
 int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
@@ -379,7 +407,7 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
   a.Ho = 2 * H;
   a.Wo = 2 * W;
   a.clamp01 = clamp01;
-  return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W, as_stream(stream));
 }
 
 }  // extern "C"
@@ -395,7 +423,7 @@ extern "C" int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_pa
   a.Ho = H / 2;
   a.Wo = W / 2;
   a.s1conv = 1;  // 3x3 stride-1 taps = output phase (0,0) of the transposed-conv kernel without the upsampling
-  return mfma_dispatch_deconv(a, MT, epilogue, W / 2, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W / 2, as_stream(stream));
 }
 
 extern "C" int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch, const float *bias, float *y_nchw,
@@ -422,5 +450,5 @@ extern "C" int licos_conv3x3s1_f16(const void *x_blk16, const void *w_packed, co
   a.Ho = H;
   a.Wo = W;
   a.s1conv = 1;
-  return mfma_dispatch_deconv(a, MT, epilogue, W, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W, as_stream(stream));
 }

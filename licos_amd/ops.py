@@ -5,6 +5,7 @@ step is one of the hand-written HIP kernels.  All wrappers refuse CPU tensors -
 there is deliberately no CPU fallback in the product.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -72,12 +73,70 @@ def query(device=0):
 
 
 # ----------------------------------------------------------------------------- 32-bit path
+# ---------------------------------------------------------------------------------------------------------------
+# fp32 through three fp16 MFMA passes.  A 5x5 stride-2 (transposed) convolution in fp32 is the throughput kernels run
+# on split operands: x = x_hi + 2^-11 x_lo, w = w_hi + 2^-11 w_lo (each part fp16, the pair carries ~22 bits), and
+#     y = x_hi*w_hi (+ bias)  +  x_hi*w_lo  +  x_lo*w_hi        (fp32 accumulation; x_lo*w_lo ~ 2^-22 is dropped)
+# Against float64 this is as accurate as torch's fp32 convolution on the CPU (max error 1e-7..1e-6 of max|y|, the
+# direct fp32 VALU kernels: up to 2e-6) and an order of magnitude faster than those kernels.  It serves the fp32
+# parity path and the training step (forward and dgrad); LICOS_FP32_MFMA=0 keeps the VALU kernels.
+FP32_MFMA = os.environ.get("LICOS_FP32_MFMA", "1") != "0"
+X3_SHIFT = 11  # residual parts are stored as fp16((v - hi) * 2^11): full 11 bits instead of fp16 subnormals
+_x3_zero_bias = {}
+
+
+def _x3_ok(cin, cout, relu):
+    """Channel counts / epilogues the MFMA kernels are instantiated for."""
+    if cin > 320 or cout > 320:
+        return False
+    return (not relu) or 32 < cout <= 192
+
+
+def _x3_weights(w, transposed):
+    """(packed hi, packed lo).  Not cached: a cache keyed on the weight's address and version would serve stale
+    fragments once a freed tensor's address is reused; the split + two packs are six tiny kernels."""
+    wf = w.detach().float()
+    hi = wf.half().float()
+    return pack_conv_w_f16(hi, transposed), pack_conv_w_f16((wf - hi) * float(2 ** X3_SHIFT), transposed)
+
+
+def nchw_f32_split_blk16(x, abs_input=False):
+    _dev(x)
+    b, c, h, w = x.shape
+    hi = torch.empty((b, (c + 15) // 16, h, w, 16), device=x.device, dtype=torch.float16)
+    lo = torch.empty_like(hi)
+    _lib.check(_lib.load().licos_nchw_f32_split_blk16(_p(_f32(x)), _p(hi), _p(lo), b, c, h, w, int(abs_input), X3_SHIFT,
+                                                      _stream()), "nchw_f32_split_blk16")
+    return hi, lo
+
+
+def _conv5x5s2_x3(x, w, bias, relu, abs_input, transposed):
+    cin = x.shape[1]
+    cout = w.shape[1] if transposed else w.shape[0]
+    xh, xl = nchw_f32_split_blk16(x.contiguous(), abs_input)
+    wh, wl = _x3_weights(w, transposed)
+    bp = pad_bias(bias, cout, x.device)
+    zk = (32 * mfma_tiles(cout), str(x.device))
+    zero = _x3_zero_bias.get(zk)
+    if zero is None:
+        zero = _x3_zero_bias[zk] = torch.zeros(zk[0], device=x.device, dtype=torch.float32)
+    fn = deconv5x5s2_f16 if transposed else conv5x5s2_f16
+    down = EPI_ACCUMULATE | (X3_SHIFT << 12)  # LICOS_EPI_SCALE_DOWN: the residual parts were scaled up by 2^X3_SHIFT
+    last = (EPI_RELU if relu else EPI_NONE) | down
+    y = fn(xh, wh, bp, None, EPI_NONE, cin, cout, out_nchw=True)
+    fn(xh, wl, zero, None, EPI_NONE | down, cin, cout, out_nchw=True, out=y)
+    fn(xl, wh, zero, None, last, cin, cout, out_nchw=True, out=y)
+    return y
+
+
 def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cout, cin_w, k, k2 = w.shape
     if cin_w != cin or k != k2:
         raise ValueError(f"conv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    if FP32_MFMA and (k, stride, pad) == (5, 2, 2) and _x3_ok(cin, cout, relu):
+        return _conv5x5s2_x3(x, w, bias, relu, abs_input, transposed=False)
     ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
     y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
     rc = _lib.load().licos_conv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride, pad,
@@ -92,6 +151,8 @@ def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False):
     cin_w, cout, k, k2 = w.shape
     if cin_w != cin or k != k2:
         raise ValueError(f"deconv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    if FP32_MFMA and (k, stride, pad, out_pad) == (5, 2, 2, 1) and _x3_ok(cin, cout, relu):
+        return _conv5x5s2_x3(x, w, bias, relu, False, transposed=True)
     ho, wo = (h - 1) * stride - 2 * pad + k + out_pad, (wd - 1) * stride - 2 * pad + k + out_pad
     y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
     rc = _lib.load().licos_deconv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride,
@@ -322,6 +383,7 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
 
 # ----------------------------------------------------------------------------- 16-bit MFMA path
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_RELU = 0, 1, 2, 3
+EPI_ACCUMULATE = 0x100  # licos_hip.h LICOS_EPI_ACCUMULATE
 
 
 def mfma_tiles(cout):

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import licos_amd
 from licos_amd import ops
@@ -417,3 +418,40 @@ def test_corrupted_strings_never_fault(precision):
     assert outcomes <= {"decoded", "rejected"} and "rejected" in outcomes
     with torch.no_grad():
         assert torch.equal(net.decompress([base], comp["shape"])["x_hat"], good)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,transposed,relu,scale", [
+    (128, 128, 64, 64, False, False, 1.0), (3, 128, 64, 64, False, False, 0.5), (128, 192, 32, 32, False, False, 5.0),
+    (128, 128, 32, 32, False, True, 0.01), (192, 128, 16, 16, True, False, 3.0), (128, 128, 32, 32, True, True, 1.0),
+    (128, 3, 32, 32, True, False, 1.0), (320, 192, 8, 8, True, False, 1.0), (13, 128, 37, 53, False, False, 1.0)])
+def test_fp32_through_three_fp16_mfma_passes(cin, cout, h, w, transposed, relu, scale):
+    """conv2d_f32 / deconv2d_f32 route 5x5 stride-2 layers through the MFMA kernels on split operands
+    (x = hi + 2^-11 lo, w likewise; hi*hi + hi*lo + lo*hi, fp32 accumulation).  Judged against float64: at least as
+    accurate as the direct fp32 VALU kernels and within a small factor of torch's own fp32 convolution."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(2, cin, h, w, generator=g) * scale
+    wshape = (cin, cout, 5, 5) if transposed else (cout, cin, 5, 5)
+    wt = torch.randn(*wshape, generator=g) * 0.03
+    b = torch.randn(cout, generator=g)
+    if transposed:
+        ref64 = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=2, output_padding=1)
+        ref32 = F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+        run = lambda: ops.deconv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), 2, 2, 1, relu)
+    else:
+        ref64 = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=2)
+        ref32 = F.conv2d(x, wt, b, stride=2, padding=2)
+        run = lambda: ops.conv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), 2, 2, relu)
+    if relu:
+        ref64, ref32 = ref64.relu(), ref32.relu()
+    saved = ops.FP32_MFMA
+    try:
+        ops.FP32_MFMA = True
+        y3 = run().cpu()
+        ops.FP32_MFMA = False
+        yv = run().cpu()
+    finally:
+        ops.FP32_MFMA = saved
+    den = float(ref64.abs().max())
+    e3, ev, e32 = (float((t.double() - ref64).abs().max()) / den for t in (y3, yv, ref32))
+    assert y3.shape == ref32.shape
+    assert e3 < 2e-6 and e3 <= max(ev, 3 * e32) + 1e-7, (e3, ev, e32)

@@ -85,19 +85,24 @@ X3_SHIFT = 11  # residual parts are stored as fp16((v - hi) * 2^11): full 11 bit
 _x3_zero_bias = {}
 
 
-def _x3_ok(cin, cout, relu):
+def _x3_ok(cin, cout, relu, kind):
     """Channel counts / epilogues the MFMA kernels are instantiated for."""
     if cin > 320 or cout > 320:
         return False
-    return (not relu) or 32 < cout <= 192
+    if not relu:
+        return True
+    return 32 < cout <= (192 if kind == "conv" else 320)  # ReLU: 4- and 6-tile kernels; 10 tiles only stride 1 / transposed
 
 
-def _x3_weights(w, transposed):
+def _x3_weights(w, kind):
     """(packed hi, packed lo).  Not cached: a cache keyed on the weight's address and version would serve stale
     fragments once a freed tensor's address is reused; the split + two packs are six tiny kernels."""
     wf = w.detach().float()
     hi = wf.half().float()
-    return pack_conv_w_f16(hi, transposed), pack_conv_w_f16((wf - hi) * float(2 ** X3_SHIFT), transposed)
+    lo = (wf - hi) * float(2 ** X3_SHIFT)
+    if kind == "conv3":
+        return pack_conv3x3_w_f16(hi), pack_conv3x3_w_f16(lo)
+    return pack_conv_w_f16(hi, kind == "deconv"), pack_conv_w_f16(lo, kind == "deconv")
 
 
 def nchw_f32_split_blk16(x, abs_input=False):
@@ -110,17 +115,19 @@ def nchw_f32_split_blk16(x, abs_input=False):
     return hi, lo
 
 
-def _conv5x5s2_x3(x, w, bias, relu, abs_input, transposed):
+def _conv_x3(x, w, bias, relu, abs_input, kind):
+    """kind: "conv" (5x5 s2), "deconv" (5x5 s2 transposed, output padding 1), "conv3" (3x3 s1)."""
+    transposed = kind == "deconv"
     cin = x.shape[1]
     cout = w.shape[1] if transposed else w.shape[0]
     xh, xl = nchw_f32_split_blk16(x.contiguous(), abs_input)
-    wh, wl = _x3_weights(w, transposed)
+    wh, wl = _x3_weights(w, kind)
     bp = pad_bias(bias, cout, x.device)
     zk = (32 * mfma_tiles(cout), str(x.device))
     zero = _x3_zero_bias.get(zk)
     if zero is None:
         zero = _x3_zero_bias[zk] = torch.zeros(zk[0], device=x.device, dtype=torch.float32)
-    fn = deconv5x5s2_f16 if transposed else conv5x5s2_f16
+    fn = {"conv": conv5x5s2_f16, "deconv": deconv5x5s2_f16, "conv3": conv3x3s1_f16}[kind]
     down = EPI_ACCUMULATE | (X3_SHIFT << 12)  # LICOS_EPI_SCALE_DOWN: the residual parts were scaled up by 2^X3_SHIFT
     last = (EPI_RELU if relu else EPI_NONE) | down
     y = fn(xh, wh, bp, None, EPI_NONE, cin, cout, out_nchw=True)
@@ -135,8 +142,10 @@ def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
     cout, cin_w, k, k2 = w.shape
     if cin_w != cin or k != k2:
         raise ValueError(f"conv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
-    if FP32_MFMA and (k, stride, pad) == (5, 2, 2) and _x3_ok(cin, cout, relu):
-        return _conv5x5s2_x3(x, w, bias, relu, abs_input, transposed=False)
+    if FP32_MFMA and (k, stride, pad) == (5, 2, 2) and _x3_ok(cin, cout, relu, "conv"):
+        return _conv_x3(x, w, bias, relu, abs_input, "conv")
+    if FP32_MFMA and (k, stride, pad) == (3, 1, 1) and _x3_ok(cin, cout, relu, "conv3"):
+        return _conv_x3(x, w, bias, relu, abs_input, "conv3")
     ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
     y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
     rc = _lib.load().licos_conv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride, pad,
@@ -151,8 +160,8 @@ def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False):
     cin_w, cout, k, k2 = w.shape
     if cin_w != cin or k != k2:
         raise ValueError(f"deconv2d_f32: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
-    if FP32_MFMA and (k, stride, pad, out_pad) == (5, 2, 2, 1) and _x3_ok(cin, cout, relu):
-        return _conv5x5s2_x3(x, w, bias, relu, False, transposed=True)
+    if FP32_MFMA and (k, stride, pad, out_pad) == (5, 2, 2, 1) and _x3_ok(cin, cout, relu, "deconv"):
+        return _conv_x3(x, w, bias, relu, False, "deconv")
     ho, wo = (h - 1) * stride - 2 * pad + k + out_pad, (wd - 1) * stride - 2 * pad + k + out_pad
     y = torch.empty((b, cout, ho, wo), device=x.device, dtype=torch.float32)
     rc = _lib.load().licos_deconv2d_f32(_p(_f32(x)), _p(_f32(w)), _p(bias), _p(y), b, cin, h, wd, cout, k, stride,

@@ -420,6 +420,28 @@ def test_corrupted_strings_never_fault(precision):
         assert torch.equal(net.decompress([base], comp["shape"])["x_hat"], good)
 
 
+@pytest.mark.parametrize("cin,cout,relu,abs_in", [(192, 128, True, True), (128, 192, True, False), (128, 320, True, False), (20, 40, False, False)])
+def test_fp32_conv3x3_through_mfma_passes(cin, cout, relu, abs_in):
+    """The hyperprior's 3x3 stride-1 layers (h_a[0] on |y|, h_s[4] + ReLU) take the same three-pass route."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, 12, 20, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    ref64 = F.conv2d((x.abs() if abs_in else x).double(), wt.double(), b.double(), padding=1)
+    ref64 = ref64.relu() if relu else ref64
+    saved = ops.FP32_MFMA
+    try:
+        ops.FP32_MFMA = True
+        y3 = ops.conv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), 1, 1, relu, abs_input=abs_in).cpu()
+        ops.FP32_MFMA = False
+        yv = ops.conv2d_f32(x.to(DEV), wt.to(DEV), b.to(DEV), 1, 1, relu, abs_input=abs_in).cpu()
+    finally:
+        ops.FP32_MFMA = saved
+    den = float(ref64.abs().max())
+    e3, ev = (float((t.double() - ref64).abs().max()) / den for t in (y3, yv))
+    assert e3 < 2e-6 and e3 <= ev + 5e-7, (e3, ev)
+
+
 @pytest.mark.parametrize("cin,cout,h,w,transposed,relu,scale", [
     (128, 128, 64, 64, False, False, 1.0), (3, 128, 64, 64, False, False, 0.5), (128, 192, 32, 32, False, False, 5.0),
     (128, 128, 32, 32, False, True, 0.01), (192, 128, 16, 16, True, False, 3.0), (128, 128, 32, 32, True, True, 1.0),

@@ -127,9 +127,9 @@ __global__ __launch_bounds__(1024) void bias_grad_f32_kernel(const float *__rest
 __global__ __launch_bounds__(256) void gdn_bwd_f32_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                           const float *__restrict__ gamma, const float *__restrict__ gamma_t,
                                                           const float *__restrict__ beta, float *__restrict__ dx,
-                                                          float *__restrict__ t_out, int C, int HW, int inverse) {
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [C][64] x^2, then [C][64] t
-  float *s_sq = s_mem, *s_t = s_mem + (size_t)C * 64;
+                                                          float *__restrict__ t_out, int C, int HW, int inverse, int keep_n) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [C][64] x^2, [C][64] t, and (keep_n) [C][64] n
+  float *s_sq = s_mem, *s_t = s_mem + (size_t)C * 64, *s_n = s_mem + (size_t)2 * C * 64;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -141,32 +141,68 @@ __global__ __launch_bounds__(256) void gdn_bwd_f32_kernel(const float *__restric
     s_sq[c * 64 + lane] = v * v;
   }
   __syncthreads();
-  for (int i = wave; i < C; i += 4) {
-    const float *gr = gamma + (size_t)i * C;
-    float n = beta[i];
-    for (int j = 0; j < C; ++j) n = fmaf(gr[j], s_sq[j * 64 + lane], n);
-    const float xv = live ? x[base + (size_t)i * HW + p] : 0.f;
-    const float g = live ? dy[base + (size_t)i * HW + p] : 0.f;
-    // n^(p-1) * p: forward -1/2 * n^(-3/2); inverse +1/2 * n^(-1/2)
-    const float rs = 1.0f / sqrtf(n);
-    const float t = inverse ? 0.5f * g * xv * rs : -0.5f * g * xv * rs / n;
-    s_t[i * 64 + lane] = t;
-    if (live) t_out[base + (size_t)i * HW + p] = t;
+  // Each wave takes channels wave, wave + 4, ...; four of them share every LDS read of x^2 (or t): the dot products
+  // are LDS-read bound otherwise.  Summation order per channel is unchanged (j ascending).
+  for (int i0 = wave; i0 < C; i0 += 16) {
+    float n[4];
+    const float *gr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u;
+      gr[u] = gamma + (size_t)(i < C ? i : 0) * C;
+      n[u] = i < C ? beta[i] : 1.f;
+    }
+    for (int j = 0; j < C; ++j) {
+      const float sq = s_sq[j * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) n[u] = fmaf(gr[u][j], sq, n[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u;
+      if (i >= C) continue;
+      const float xv = live ? x[base + (size_t)i * HW + p] : 0.f;
+      const float g = live ? dy[base + (size_t)i * HW + p] : 0.f;
+      // n^(p-1) * p: forward -1/2 * n^(-3/2); inverse +1/2 * n^(-1/2)
+      const float rs = 1.0f / sqrtf(n[u]);
+      const float t = inverse ? 0.5f * g * xv * rs : -0.5f * g * xv * rs / n[u];
+      s_t[i * 64 + lane] = t;
+      if (keep_n) s_n[i * 64 + lane] = n[u];
+      if (live) t_out[base + (size_t)i * HW + p] = t;
+    }
   }
   __syncthreads();
-  for (int i = wave; i < C; i += 4) {
-    const float *gc = gamma_t + (size_t)i * C;  // row i of gamma^T = column i of gamma
-    float acc = 0.f;
-    for (int k = 0; k < C; ++k) acc = fmaf(gc[k], s_t[k * 64 + lane], acc);
-    if (live) {
+  for (int i0 = wave; i0 < C; i0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, n[4];
+    const float *gc[4], *gr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u;
+      gc[u] = gamma_t + (size_t)(i < C ? i : 0) * C;  // row i of gamma^T = column i of gamma
+      gr[u] = gamma + (size_t)(i < C ? i : 0) * C;
+      n[u] = i < C ? beta[i] : 1.f;
+    }
+    for (int k = 0; k < C; ++k) {
+      const float tv = s_t[k * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fmaf(gc[u][k], tv, acc[u]);
+    }
+    if (!keep_n) {  // C too wide to keep n in LDS: one more dot product per channel
+      for (int j = 0; j < C; ++j) {
+        const float sq = s_sq[j * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) n[u] = fmaf(gr[u][j], sq, n[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u;
+      if (i >= C || !live) continue;
+      const float nn = keep_n ? s_n[i * 64 + lane] : n[u];
       const float xv = x[base + (size_t)i * HW + p];
       const float g = dy[base + (size_t)i * HW + p];
-      // n_i^p again (cheaper than keeping it: one dot product was the cost, recompute from s_sq)
-      const float *gr = gamma + (size_t)i * C;
-      float n = beta[i];
-      for (int j = 0; j < C; ++j) n = fmaf(gr[j], s_sq[j * 64 + lane], n);
-      const float f = inverse ? sqrtf(n) : 1.0f / sqrtf(n);
-      dx[base + (size_t)i * HW + p] = g * f + 2.0f * xv * acc;
+      const float f = inverse ? sqrtf(nn) : 1.0f / sqrtf(nn);
+      dx[base + (size_t)i * HW + p] = g * f + 2.0f * xv * acc[u];
     }
   }
 }
@@ -248,7 +284,8 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
                       float *dx, float *t_out, int B, int C, int HW, int inverse, void *stream) {
   LICOS_REQUIRE(x && dy && gamma_eff && beta_eff && gamma_t_scratch && dx && t_out, "gdn_bwd_f32: NULL buffer");
   LICOS_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0, "gdn_bwd_f32: bad shape");
-  const size_t lds = (size_t)2 * C * 64 * sizeof(float);
+  const int keep_n = (size_t)3 * C * 64 * sizeof(float) <= 160 * 1024;  // n kept in LDS between the two passes when it fits
+  const size_t lds = (size_t)(keep_n ? 3 : 2) * C * 64 * sizeof(float);
   LICOS_REQUIRE(lds <= 160 * 1024, "gdn_bwd_f32: C=%d needs %zu B of LDS", C, lds);
   hipLaunchKernelGGL(transpose_sq_f32_kernel, dim3(cdiv((long)C * C, 256)), dim3(256), 0, as_stream(stream), gamma_eff,
                      gamma_t_scratch, C);
@@ -259,7 +296,7 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
     attr_set = true;
   }
   hipLaunchKernelGGL(gdn_bwd_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, dy, gamma_eff,
-                     gamma_t_scratch, beta_eff, dx, t_out, C, HW, inverse);
+                     gamma_t_scratch, beta_eff, dx, t_out, C, HW, inverse, keep_n);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

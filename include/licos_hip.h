@@ -278,6 +278,18 @@ int licos_pack_deconv_w_scatter_f16(const float *w /*[Cin][Cout][5][5]*/, int Ci
 int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scatter, const float *bias, float *y_nchw,
                                   int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
 
+/* Weight gradient of a 5x5 stride-2 Conv2d / ConvTranspose2d (licos/train.py:195 loss.backward()) on the matrix cores:
+ *   dw[s][c][ky][kx] += 2^-scale_down * sum_{b,y,x} small[b][s][y][x] * large[b][c][2y+ky-2][2x+kx-2]
+ * small = the conv's output gradient (s = cout) or the transposed conv's input (s = cin); large = the conv's input
+ * or the transposed conv's output gradient.  Both maps are "batch-minor" fp16: [ceil(B/16)][H][W][2][channel][8 images]
+ * (licos_nchw_f32_split_bm8: hi = fp16(x), lo = fp16((x - hi) * 2^lo_shift)).  dw: fp32, accumulated (caller zeroes).
+ * The small map's rows are cut into licos_wgrad5x5s2_strips(Cs, Cl, Hs) strips whose partial sums go through
+ * `scratch` (strips * Cs * Cl * 25 floats) and are added in strip order: no atomics, bit-reproducible. */
+int licos_nchw_f32_split_bm8(const float *x, void *y_hi, void *y_lo, int B, int C, int H, int W, int lo_shift, void *stream);
+int licos_wgrad5x5s2_strips(int Cs, int Cl, int Hs);
+int licos_wgrad5x5s2_f16(const void *small_bm8, const void *large_bm8, float *scratch, float *dw, int Cs, int Cl, int nbc, int Hs,
+                         int Ws, int Hl, int Wl, int scale_down, void *stream);
+
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1
 #define LICOS_EPI_IGDN 2

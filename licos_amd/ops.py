@@ -196,10 +196,43 @@ def conv2d_wgrad_f32(inp, g, ci, co, k, stride, pad, square_input=False):
     """dw [co][ci][k][k] = sum g[b][co][oy][ox] * inp[b][ci][oy*s-p+ky][ox*s-p+kx]."""
     _dev(inp, g)
     b, _, h, w = inp.shape
+    if WGRAD_MFMA and FP32_MFMA and (k, stride, pad) == (5, 2, 2) and not square_input:
+        return _wgrad5x5s2_x3(inp, g, ci, co)
     dw = torch.empty((co, ci, k, k), device=inp.device, dtype=torch.float32)
     rc = _lib.load().licos_conv2d_wgrad_f32(_p(_f32(inp)), _p(_f32(g)), _p(dw), b, ci, h, w, co, k, stride, pad,
                                             int(square_input), _stream())
     _lib.check(rc, "conv2d_wgrad_f32")
+    return dw
+
+
+WGRAD_MFMA = os.environ.get("LICOS_WGRAD_MFMA", "1") != "0"
+
+
+def _split_bm8(x):
+    """NCHW fp32 -> batch-minor fp16 pair [ceil(B/16)][H][W][2][C][8] (hi, 2^11-scaled residual)."""
+    b, c, h, w = x.shape
+    shape = ((b + 15) // 16, h, w, 2, c, 8)
+    hi = torch.empty(shape, device=x.device, dtype=torch.float16)
+    lo = torch.empty(shape, device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_nchw_f32_split_bm8(_p(_f32(x)), _p(hi), _p(lo), b, c, h, w, X3_SHIFT, _stream()),
+               "nchw_f32_split_bm8")
+    return hi, lo
+
+
+def _wgrad5x5s2_x3(inp, g, ci, co):
+    """The same weight gradient on the matrix cores: both maps in batch-minor fp16 (the 16 images of a pixel = one
+    MFMA K step), split hi / 2^-11 lo, three passes, per-strip partial sums added in a fixed order."""
+    b, _, hl, wl = inp.shape
+    hs, ws = g.shape[2:]
+    nbc = (b + 15) // 16
+    l_hi, l_lo = _split_bm8(inp.detach().contiguous())
+    s_hi, s_lo = _split_bm8(g.detach().contiguous())
+    dw = torch.zeros((co, ci, 5, 5), device=inp.device, dtype=torch.float32)
+    lib = _lib.load()
+    scratch = torch.empty(lib.licos_wgrad5x5s2_strips(co, ci, hs) * co * ci * 25, device=inp.device, dtype=torch.float32)
+    for small, large, down in ((s_hi, l_hi, 0), (s_hi, l_lo, X3_SHIFT), (s_lo, l_hi, X3_SHIFT)):
+        rc = lib.licos_wgrad5x5s2_f16(_p(small), _p(large), _p(scratch), _p(dw), co, ci, nbc, hs, ws, hl, wl, down, _stream())
+        _lib.check(rc, "wgrad5x5s2_f16")
     return dw
 
 

@@ -192,3 +192,30 @@ def test_hyperprior_training_reaches_every_parameter():
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
     for name in ("g_a.0.weight", "h_a.0.weight", "h_s.0.weight", "g_s.0.weight"):
         assert float(dict(net.named_parameters())[name].grad.abs().max()) > 0.0, name
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [(128, 128, 32, 32, 16), (13, 128, 40, 24, 5), (128, 3, 16, 16, 20), (192, 320, 8, 8, 16)])
+def test_mfma_weight_gradient_accuracy_and_reproducibility(cin, cout, h, w, batch):
+    """5x5 stride-2 weight gradient on the matrix cores (three split-operand passes, per-strip partial sums added in a
+    fixed order): against float64 as good as the fp32 VALU kernel, and bit-identical from run to run (no atomics)."""
+    from licos_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + batch)
+    x = torch.randn(batch, cin, h, w, generator=g)
+    dy = torch.randn(batch, cout, h // 2, w // 2, generator=g)
+    wt = torch.zeros(cout, cin, 5, 5, dtype=torch.float64, requires_grad=True)
+    F = torch.nn.functional
+    (F.conv2d(x.double(), wt, None, stride=2, padding=2) * dy.double()).sum().backward()
+    ref = wt.grad
+    saved = ops.WGRAD_MFMA
+    try:
+        ops.WGRAD_MFMA = True
+        a = ops.conv2d_wgrad_f32(x.to(DEV), dy.to(DEV), cin, cout, 5, 2, 2)
+        b = ops.conv2d_wgrad_f32(x.to(DEV), dy.to(DEV), cin, cout, 5, 2, 2)
+        ops.WGRAD_MFMA = False
+        v = ops.conv2d_wgrad_f32(x.to(DEV), dy.to(DEV), cin, cout, 5, 2, 2)
+    finally:
+        ops.WGRAD_MFMA = saved
+    assert torch.equal(a, b)
+    den = float(ref.abs().max())
+    ea, ev = (float((t.cpu().double() - ref).abs().max()) / den for t in (a, v))
+    assert ea < 3e-6 and ea <= 2 * ev + 5e-7, (ea, ev)

@@ -132,11 +132,19 @@ __global__ void nchw_to_s2d_blk16_kernel(const float *__restrict__ x, _Float16 *
     const int cc = (int)((e / ((long)W2 * H2)) % C16);
     const long b = e / ((long)W2 * H2 * C16);
     half8 lo, hi;
+    // s2d channel kidx = 4c + 2py + px: the two px of a (c, py) pair are adjacent in memory - one 8-byte load
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int kidx = cc * 16 + j, c = kidx >> 2, py = (kidx >> 1) & 1, px = kidx & 1;
-      const float v = (c < C) ? x[(((size_t)b * C + c) * H + 2 * y2 + py) * W + 2 * x2 + px] : 0.f;
-      if (j < 8) lo[j] = (_Float16)v; else hi[j - 8] = (_Float16)v;
+    for (int jp = 0; jp < 8; ++jp) {
+      const int kidx = cc * 16 + 2 * jp, c = kidx >> 2, py = (kidx >> 1) & 1;
+      float2 v = make_float2(0.f, 0.f);
+      if (c < C) v = *reinterpret_cast<const float2 *>(x + (((size_t)b * C + c) * H + 2 * y2 + py) * W + 2 * x2);
+      if (jp < 4) {
+        lo[2 * jp] = (_Float16)v.x;
+        lo[2 * jp + 1] = (_Float16)v.y;
+      } else {
+        hi[2 * jp - 8] = (_Float16)v.x;
+        hi[2 * jp - 7] = (_Float16)v.y;
+      }
     }
     half8 *dst = reinterpret_cast<half8 *>(y + (size_t)e * 16);
     dst[0] = lo;
@@ -275,6 +283,7 @@ int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float bet
 
 int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
   LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "nchw_f32_to_s2d_blk16: bad arguments (H, W must be even)");
+  LICOS_REQUIRE(((uintptr_t)x & 7) == 0, "nchw_f32_to_s2d_blk16: input must be 8-byte aligned");
   const int C16 = (4 * C + 15) / 16;
   const long total = (long)B * C16 * (H / 2) * (W / 2);
   hipLaunchKernelGGL(nchw_to_s2d_blk16_kernel, dim3(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192), dim3(256), 0,

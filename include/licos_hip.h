@@ -254,7 +254,8 @@ int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, 
  * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
  * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the
  * strided halo patch into a one-pixel halo.  H, W (even) are the ORIGINAL image size. */
-/* As licos_nchw_f32_to_blk16, plus the residual y_lo = fp16((x - float(y_hi)) * 2^lo_shift). */
+/* As licos_nchw_f32_to_blk16, plus the residual y_lo = fp16((x - float(y_hi)) * 2^lo_shift).  abs_input: bit 0 |x|,
+ * bit 1 (x / 16)^2 (the GDN norm operand: gamma is then passed multiplied by 256). */
 int licos_nchw_f32_split_blk16(const float *x, void *y_hi_blk16, void *y_lo_blk16, int B, int C, int H, int W, int abs_input,
                                int lo_shift, void *stream);
 int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
@@ -277,6 +278,18 @@ size_t licos_packed_deconv_w_scatter_bytes(int Cin, int Cout);
 int licos_pack_deconv_w_scatter_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scatter, const float *bias, float *y_nchw,
                                   int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
+
+/* 1x1 convolution on the matrix cores, NCHW fp32 output: the channel product of GDN / IGDN ([CAI] layers/gdn.py:
+ * norm = conv2d(x^2, gamma, beta)) and of its backward pass (gamma^T . t), as three split-operand passes (`epilogue` =
+ * LICOS_EPI_NONE, then LICOS_EPI_ACCUMULATE | LICOS_EPI_SCALE_DOWN(k)).  w: [Cout][Cin] fp32 row-major.  Instantiated
+ * for 128 and 192 channels.  licos_gdn_pointwise_f32 supplies the element-wise halves: mode 0 y = x n^p, mode 1
+ * t = dy x p n^(p-1), mode 2 dx = dy n^p + 2 x u (p = -1/2, or +1/2 with `inverse`). */
+size_t licos_packed_conv1x1_w_bytes(int Cin, int Cout);
+int licos_pack_conv1x1_w_f16(const float *w /*[Cout][Cin]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_conv1x1_f16(const void *x_blk16, const void *w_packed, const float *bias, int epilogue, float *y_nchw, int B, int Cin,
+                      int H, int W, int Cout, void *stream);
+int licos_gdn_pointwise_f32(const float *x, const float *n, const float *dy, const float *u, float *out, long count, int inverse,
+                            int mode, void *stream);
 
 /* Weight gradient of a 5x5 stride-2 Conv2d / ConvTranspose2d (licos/train.py:195 loss.backward()) on the matrix cores:
  *   dw[s][c][ky][kx] += 2^-scale_down * sum_{b,y,x} small[b][s][y][x] * large[b][c][2y+ky-2][2x+kx-2]

@@ -61,6 +61,10 @@ SIGNATURES = {
     "licos_pack_deconv_w_scatter_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_deconv5x5s2_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_nchw_f32_to_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_packed_conv1x1_w_bytes": (_c.c_size_t, [_i, _i]),
+    "licos_pack_conv1x1_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "licos_conv1x1_f16": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_gdn_pointwise_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "licos_nchw_f32_split_bm8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_wgrad5x5s2_strips": (_i, [_i, _i, _i]),
     "licos_wgrad5x5s2_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -207,6 +207,27 @@ __global__ __launch_bounds__(256) void gdn_bwd_f32_kernel(const float *__restric
   }
 }
 
+// ---- GDN around an MFMA norm product (licos_conv1x1_f16): the element-wise halves ------------------------------
+// mode 0: y = x * n^p                        (p = -1/2, +1/2 for the inverse)
+// mode 1: t = dy * x * p * n^(p-1)           (dL/dn; also what dgamma / dbeta are reduced from)
+// mode 2: dx = dy * n^p + 2 x u              (u = gamma^T . t)
+__global__ void gdn_pointwise_f32_kernel(const float *__restrict__ x, const float *__restrict__ n, const float *__restrict__ dy,
+                                         const float *__restrict__ u, float *__restrict__ out, long count, int inverse, int mode) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+    const float nn = n[e], xv = x[e];
+    const float rs = 1.0f / sqrtf(nn);
+    if (mode == 0) {
+      out[e] = inverse ? xv * sqrtf(nn) : xv * rs;
+    } else if (mode == 1) {
+      const float g = dy[e];
+      out[e] = inverse ? 0.5f * g * xv * rs : -0.5f * g * xv * rs / nn;
+    } else {
+      const float f = inverse ? sqrtf(nn) : rs;
+      out[e] = dy[e] * f + 2.0f * xv * u[e];
+    }
+  }
+}
+
 // NonNegativeParametrizer backward: eff = max(raw, bound)^2 - pedestal with CompressAI's LowerBound gradient
 // (passes where raw >= bound or the incoming gradient is negative):  d_raw = pass ? d_eff * 2 * max(raw, bound) : 0
 __global__ void reparam_bwd_f32_kernel(const float *__restrict__ raw, const float *__restrict__ d_eff, float bound,
@@ -297,6 +318,17 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
   }
   hipLaunchKernelGGL(gdn_bwd_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, dy, gamma_eff,
                      gamma_t_scratch, beta_eff, dx, t_out, C, HW, inverse, keep_n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gdn_pointwise_f32(const float *x, const float *n, const float *dy, const float *u, float *out, long count, int inverse,
+                            int mode, void *stream) {
+  LICOS_REQUIRE(x && n && out && count > 0 && mode >= 0 && mode <= 2, "gdn_pointwise_f32: bad arguments");
+  LICOS_REQUIRE(mode == 0 || dy, "gdn_pointwise_f32: modes 1 and 2 need dy");
+  LICOS_REQUIRE(mode != 2 || u, "gdn_pointwise_f32: mode 2 needs u");
+  const int blocks = (int)((count + 255) / 256 < 16384 ? (count + 255) / 256 : 16384);
+  hipLaunchKernelGGL(gdn_pointwise_f32_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n, dy, u, out, count, inverse, mode);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

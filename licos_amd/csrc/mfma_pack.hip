@@ -184,7 +184,11 @@ __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__re
       const int c0 = cc * 16 + j, c1 = c0 + 8;
       float v0 = (c0 < C) ? x[((size_t)b * C + c0) * HW + p] : 0.f;
       float v1 = (c1 < C) ? x[((size_t)b * C + c1) * HW + p] : 0.f;
-      if (abs_input) { v0 = fabsf(v0); v1 = fabsf(v1); }
+      if (abs_input & 1) { v0 = fabsf(v0); v1 = fabsf(v1); }
+      if (abs_input & 2) {  // (x / 16)^2: the GDN norm operand, pre-scaled so that |x| up to ~4000 stays inside fp16
+        v0 *= 0.0625f; v1 *= 0.0625f;
+        v0 *= v0; v1 *= v1;
+      }
       lo[j] = (_Float16)v0;
       hi[j] = (_Float16)v1;
       rlo[j] = (_Float16)((v0 - (float)lo[j]) * res_scale);  // scaled up so the residual keeps all 11 bits (no fp16 subnormals)

@@ -105,12 +105,13 @@ def _x3_weights(w, kind):
     return pack_conv_w_f16(hi, kind == "deconv"), pack_conv_w_f16(lo, kind == "deconv")
 
 
-def nchw_f32_split_blk16(x, abs_input=False):
+def nchw_f32_split_blk16(x, abs_input=False, square16=False):
+    """(hi, lo) blk16 fp16 parts of x (|x| with abs_input; (x/16)^2 with square16 - the GDN norm operand)."""
     _dev(x)
     b, c, h, w = x.shape
     hi = torch.empty((b, (c + 15) // 16, h, w, 16), device=x.device, dtype=torch.float16)
     lo = torch.empty_like(hi)
-    _lib.check(_lib.load().licos_nchw_f32_split_blk16(_p(_f32(x)), _p(hi), _p(lo), b, c, h, w, int(abs_input), X3_SHIFT,
+    _lib.check(_lib.load().licos_nchw_f32_split_blk16(_p(_f32(x)), _p(hi), _p(lo), b, c, h, w, int(bool(abs_input)) | (2 if square16 else 0), X3_SHIFT,
                                                       _stream()), "nchw_f32_split_blk16")
     return hi, lo
 
@@ -181,10 +182,52 @@ def gdn_reparam_f32(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
     return beta, gamma
 
 
+GDN_MFMA = os.environ.get("LICOS_GDN_MFMA", "1") != "0"
+
+
+def _conv1x1_x3(x, w, bias, square16=False):
+    """y = bias + w . x over channels (NCHW fp32 in and out) as three split-operand MFMA passes; with square16 the
+    operand is (x/16)^2 and w must already carry the factor 256."""
+    b, c, h, wd = x.shape
+    cout = w.shape[0]
+    xh, xl = nchw_f32_split_blk16(x.contiguous(), square16=square16)
+    wf = w.detach().float().contiguous()
+    hi = wf.half().float()
+    lib = _lib.load()
+    packs = []
+    for part in (hi, (wf - hi) * float(2 ** X3_SHIFT)):
+        pk = torch.empty(lib.licos_packed_conv1x1_w_bytes(c, cout) // 2, device=x.device, dtype=torch.float16)
+        _lib.check(lib.licos_pack_conv1x1_w_f16(_p(part), c, cout, _p(pk), _stream()), "pack_conv1x1_w_f16")
+        packs.append(pk)
+    bp = pad_bias(bias, cout, x.device)
+    zk = (32 * mfma_tiles(cout), str(x.device))
+    zero = _x3_zero_bias.get(zk)
+    if zero is None:
+        zero = _x3_zero_bias[zk] = torch.zeros(zk[0], device=x.device, dtype=torch.float32)
+    y = torch.empty((b, cout, h, wd), device=x.device, dtype=torch.float32)
+    down = EPI_ACCUMULATE | (X3_SHIFT << 12)
+    for xin, pk, bb, epi in ((xh, packs[0], bp, EPI_NONE), (xh, packs[1], zero, down), (xl, packs[0], zero, down)):
+        _lib.check(lib.licos_conv1x1_f16(_p(xin), _p(pk), _p(bb), epi, _p(y), b, c, h, wd, cout, _stream()), "conv1x1_f16")
+    return y
+
+
+def _gdn_pointwise(x, n, dy, u, inverse, mode):
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().licos_gdn_pointwise_f32(_p(x), _p(n), _p(dy), _p(u), _p(out), x.numel(), int(inverse), mode, _stream()),
+               "gdn_pointwise_f32")
+    return out
+
+
+def _gdn_mfma_ok(x):
+    return GDN_MFMA and FP32_MFMA and x.dim() == 4 and x.shape[1] in (128, 192)
+
+
 def gdn_f32(x, gamma_eff, beta_eff, inverse=False):
     _dev(x, gamma_eff, beta_eff)
     b, c = x.shape[:2]
     hw = x[0, 0].numel()
+    # (the forward stays on the direct kernel: one product, and the VALU kernel does it as fast as three MFMA passes
+    # plus operand splitting; the backward, two products per element, is where the matrix cores pay - gdn_bwd_f32)
     y = torch.empty_like(x)
     rc = _lib.load().licos_gdn_f32(_p(_f32(x)), _p(gamma_eff), _p(beta_eff), _p(y), b, c, hw, int(inverse), _stream())
     _lib.check(rc, "gdn_f32")
@@ -248,6 +291,12 @@ def gdn_bwd_f32(x, dy, gamma_eff, beta_eff, inverse):
     _dev(x, dy, gamma_eff, beta_eff)
     b, c = x.shape[:2]
     hw = x[0, 0].numel()
+    if _gdn_mfma_ok(x):
+        x, dy = _f32(x).contiguous(), _f32(dy).contiguous()
+        n = _conv1x1_x3(x, gamma_eff * 256.0, beta_eff, square16=True)
+        t = _gdn_pointwise(x, n, dy, None, inverse, 1)                       # dL/dn
+        u = _conv1x1_x3(t, gamma_eff.t().contiguous(), None)                 # gamma^T . t
+        return _gdn_pointwise(x, n, dy, u, inverse, 2), t
     dx, t = torch.empty_like(x), torch.empty_like(x)
     scratch = torch.empty_like(gamma_eff)
     rc = _lib.load().licos_gdn_bwd_f32(_p(_f32(x)), _p(_f32(dy)), _p(gamma_eff), _p(beta_eff), _p(scratch), _p(dx), _p(t),

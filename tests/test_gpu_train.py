@@ -105,14 +105,16 @@ def test_deconv_backward_kernels(cin, cout, h, w):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
-def test_gdn_backward_kernel(inverse):
-    c = 128
+@pytest.mark.parametrize("c,scale", [(128, 2.0), (192, 2.0), (128, 300.0), (64, 2.0)])
+def test_gdn_backward_kernel(inverse, c, scale):
+    """128 / 192 channels take the matrix-core route (norm and gamma^T.t as split-operand 1x1 products, the norm operand
+    pre-scaled as (x/16)^2 so that activations in the hundreds stay inside fp16); other widths the direct kernel."""
     g = torch.Generator().manual_seed(5)
     sd = {}
     om._gdn_init(sd, "g.", c)
     sd["g.gamma"] = (sd["g.gamma"] + 0.05 * torch.rand(c, c, generator=g))
     sd["g.beta"] = sd["g.beta"] * (0.5 + torch.rand(c, generator=g))
-    x = (2 * torch.randn(2, c, 9, 11, generator=g)).requires_grad_(True)
+    x = (scale * torch.randn(2, c, 9, 11, generator=g)).requires_grad_(True)
     ref_sd = dict(sd)
     ref_sd["g.gamma"] = sd["g.gamma"].clone().requires_grad_(True)
     ref_sd["g.beta"] = sd["g.beta"].clone().requires_grad_(True)

@@ -250,14 +250,15 @@ int licos_conv3x3s1_f16(const void *x_blk16, const void *w_packed, const float *
                         void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout, void *stream);
 int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, int W, void *stream);
 
-/* First analysis stage for few input channels (Cin <= 4: RGB, single Sentinel-2 band): a 5x5 stride-2 conv over
- * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
- * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the
- * strided halo patch into a one-pixel halo.  H, W (even) are the ORIGINAL image size. */
 /* As licos_nchw_f32_to_blk16, plus the residual y_lo = fp16((x - float(y_hi)) * 2^lo_shift).  abs_input: bit 0 |x|,
  * bit 1 (x / 16)^2 (the GDN norm operand: gamma is then passed multiplied by 256). */
 int licos_nchw_f32_split_blk16(const float *x, void *y_hi_blk16, void *y_lo_blk16, int B, int C, int H, int W, int abs_input,
                                int lo_shift, void *stream);
+
+/* First analysis stage for few input channels (Cin <= 4: RGB, single Sentinel-2 band): a 5x5 stride-2 conv over
+ * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
+ * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the
+ * strided halo patch into a one-pixel halo.  H, W (even) are the ORIGINAL image size. */
 int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream);
 int licos_pack_conv_w_s2d_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, const float *bias,

@@ -24,7 +24,7 @@ namespace licos {
 struct WgradArgs {
   const half8 *small;  // [nbc][Hs][Ws][2][Cs] granules of 8 images
   const half8 *large;  // [nbc][Hl][Wl][2][Cl]
-  float *part;         // [n_strips][Cs][Cl][25] per-strip partial sums
+  float *part;         // [n_strips][25][Cs][Cl] per-strip partial sums (tap-major: a wave stores 128-byte rows)
   int Cs, Cl, nbc, Hs, Ws, Hl, Wl, rows_per_strip;
 };
 
@@ -104,17 +104,20 @@ __global__ __launch_bounds__(64, 2) void wgrad5x5s2_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int cs = cs0 + 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (cs < a.Cs) mine[((size_t)cs * a.Cl + cl) * 25 + tap0 + t] = acc[mt][t][q];
+        if (cs < a.Cs) mine[((size_t)(tap0 + t) * a.Cs + cs) * a.Cl + cl] = acc[mt][t][q];
       }
     }
 }
 
-// dw[i] += scale * sum over strips (in order) of part[strip][i]
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int n_strips, float scale) {
+// dw[cs][cl][tap] += scale * sum over strips (in order) of part[strip][tap][cs][cl]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int n_strips, float scale,
+                                    long cscl) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long tap = i / cscl, pair = i - tap * cscl;  // i walks the partials' layout: coalesced reads
     float sum = 0.f;
     for (int s = 0; s < n_strips; ++s) sum += part[(size_t)s * n + i];
-    dw[i] = fmaf(sum, scale, dw[i]);
+    float *d = dw + pair * 25 + tap;
+    *d = fmaf(sum, scale, *d);
   }
 }
 
@@ -202,7 +205,7 @@ extern "C" int licos_wgrad5x5s2_f16(const void *small_bm8, const void *large_bm8
   LICOS_LAUNCH_CHECK();
   const long n = (long)Cs * Cl * 25;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), scratch, dw, n, n_strips,
-                     ldexpf(1.f, -scale_down));
+                     ldexpf(1.f, -scale_down), (long)Cs * Cl);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -4,8 +4,10 @@ A transform (``g_a`` / ``g_s``) is a chain of (conv | deconv)[+ GDN] stages.  Ea
 HIP kernel (licos_amd/csrc/mfma_{conv,deconv}.hip) reading and writing the blk16 fp16 layout; only
 the two ends of the chain touch NCHW fp32.  Packed operands (MFMA weight fragments, padded bias,
 reparametrised bf16 gamma fragments) are cached per module and rebuilt when a parameter's
-version or storage changes - so modules swapped in after construction (model_utils.py:31-45) and
-optimiser steps are picked up lazily.
+version or storage changes or when the package's weights epoch moves (ops.touch_weights: the fused
+Adam, the federated average and every other raw-pointer writer bump it, since torch's version counter
+does not see their writes) - so modules swapped in after construction (model_utils.py:31-45),
+optimiser steps and averaging steps are all picked up lazily.
 """
 import os
 import weakref
@@ -36,7 +38,7 @@ def _timed(key, fn):
 
 
 def _pver(p):
-    return None if p is None else (p.data_ptr(), p._version, str(p.device))
+    return None if p is None else (p.data_ptr(), p._version, str(p.device), ops.weights_epoch())
 
 
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage

@@ -190,7 +190,8 @@ class EntropyBottleneck(nn.Module):
 
     # ------------------------------------------------------------------ device path
     def packed_params(self):
-        key = tuple((p.data_ptr(), p._version) for p in list(self.matrices) + list(self.biases) + list(self.factors))
+        key = (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in
+                                              list(self.matrices) + list(self.biases) + list(self.factors))
         if self._packed_key != key:
             self._packed = ops.eb_pack([m.detach() for m in self.matrices], [b.detach() for b in self.biases],
                                        [f.detach() for f in self.factors], self.filters, self.channels)

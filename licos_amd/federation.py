@@ -15,8 +15,8 @@ Uniform coefficients give plain FedAvg.  Every rank ends with the central model 
 leaves rank r with the central model *as of its visit*; documented difference).
 
 Integer buffers (the entropy coder's tables) are not averaged: blending them is the identity
-in exact arithmetic and a truncation hazard in floating point; call ``net.update(force=True)``
-after averaging to rebuild them from the averaged parameters.
+in exact arithmetic and a truncation hazard in floating point; ``update_central_model`` rebuilds
+them from the averaged parameters (``net.update(force=True)``) when the model carries tables.
 """
 import torch
 import torch.distributed as dist
@@ -82,7 +82,19 @@ def weighted_average_(flat_state, coef, group=None):
             ops.scale_f32(flat[: flat_state.numel], 1.0, inv_alpha_dev=flat[flat_state.numel:])
         else:
             flat[: flat_state.numel].div_(flat[-1])
+    # parameters are views of the bucket and neither the kernels nor the collective move their version counters:
+    # tell every packed-operand cache (engine.py, layers.py, entropy_models.py) that the weights changed
+    ops.touch_weights()
     return flat_state
+
+
+def _gather_scalars(values, world, rank, device, group):
+    """[world][len(values)] float64 on the host.  One all-reduce of a one-hot-by-rank matrix: works on every backend
+    (gloo has no all_gather for device tensors, RCCL none for host tensors)."""
+    t = torch.zeros((world, len(values)), dtype=torch.float64, device=device)
+    t[rank] = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu()
 
 
 def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_time, cfg=None, flat_state=None,
@@ -97,12 +109,14 @@ def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_ti
     if uniform or world == 1:
         coef = 1.0
     else:
-        mine = torch.tensor([loss, best_loss], dtype=torch.float64, device=flat_state.flat.device)
-        allv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine, group=group)
-        vals = torch.stack(allv).cpu()
-        coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[dist.get_rank(group)]
+        r = dist.get_rank(group)
+        vals = _gather_scalars([loss, best_loss], world, r, flat_state.flat.device, group)
+        coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[r]
     weighted_average_(flat_state, coef, group=group)
+    # the integer coder tables are functions of the (now averaged) parameters: rebuild them when the model carries any,
+    # so that neither the module nor the checkpoint written below pairs new weights with old tables
+    if any(getattr(m, "_offset", None) is not None and m._offset.numel() > 0 for m in net.modules()):
+        net.update(force=True)
     # the reference leaves the averaged model on disk as the "central model" (federation_utils.py:58-83); with a
     # collective every rank holds it already, so one rank writes the same file for eval_script.py to pick up
     save_path = _cfg_get(cfg, "save_path")
@@ -132,6 +146,8 @@ def clock_sync(running=1, group=None, device=None):
     (licos/main.py:96-107, :259-263): number of ranks still running."""
     if not (dist.is_available() and dist.is_initialized()):
         return running
+    if device is None and dist.get_backend(group) == "nccl":  # RCCL reduces device memory only
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([running], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())

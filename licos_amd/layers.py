@@ -67,8 +67,8 @@ class GDN(nn.Module):
                 self.beta_reparam.pedestal_value)
 
     def effective(self):
-        """Reparametrised (beta, gamma) on the device, cached per parameter version."""
-        key = (self.beta.data_ptr(), self.beta._version, self.gamma.data_ptr(), self.gamma._version)
+        """Reparametrised (beta, gamma) on the device, cached per parameter version and weights epoch."""
+        key = (self.beta.data_ptr(), self.beta._version, self.gamma.data_ptr(), self.gamma._version, ops.weights_epoch())
         if self._eff_key != key:
             bb, gb, ped = self.reparam_args()
             self._eff = ops.gdn_reparam_f32(self.beta.detach(), self.gamma.detach(), bb, gb, ped)

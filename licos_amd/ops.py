@@ -40,6 +40,23 @@ def _f32(t):
     return t
 
 
+# ----------------------------------------------------------------------------- weights epoch
+# The kernels behind adam_f32 / scale_f32 (and any collective on a FlatState bucket) write parameter memory through raw
+# pointers, which torch's per-tensor version counter never sees.  Every cache of packed operands (engine.py, layers.py,
+# entropy_models.py) therefore keys on this package-level epoch as well; every raw-pointer writer bumps it.
+_weights_epoch = 0
+
+
+def weights_epoch():
+    return _weights_epoch
+
+
+def touch_weights():
+    """Declare that parameter memory may have changed behind torch's back (invalidates all packed-operand caches)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
 # ----------------------------------------------------------------------------- host-side helpers
 def pmf_to_quantized_cdf(pmf, precision=16):
     """CompressAI ``_CXX.pmf_to_quantized_cdf`` equivalent (host, int32 out)."""
@@ -318,6 +335,7 @@ def adam_f32(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     rc = _lib.load().licos_adam_f32(_p(_f32(p)), _p(_f32(g)), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step,
                                     grad_scale, _stream())
     _lib.check(rc, "adam_f32")
+    touch_weights()
 
 
 def sumsq_f32(x, out):
@@ -426,6 +444,7 @@ def scale_f32(x, alpha, inv_alpha_dev=None):
     """In place x *= alpha (or alpha / inv_alpha_dev[0])."""
     _dev(x, inv_alpha_dev)
     _lib.check(_lib.load().licos_scale_f32(_p(_f32(x)), x.numel(), float(alpha), _p(inv_alpha_dev), _stream()), "scale_f32")
+    touch_weights()
     return x
 
 

@@ -264,6 +264,51 @@ def test_fp16_codec_accepts_plain_and_edited_string_lists():
     assert np.frombuffer(np.array(comp["strings"]), dtype=np.uint8).size > 0  # eval_utils.py:202-204 idiom
 
 
+def test_mutated_packed_strings_decode_what_the_list_holds():
+    """The list compress() returns may be edited by the caller (a corruption experiment, a swap between tiles): the
+    packed host buffers it remembers are then stale and decompress must decode the list's bytes, including when the
+    replacement has the SAME length as the original (the round-1 check sampled three lengths per segment)."""
+    from licos_amd.codec import PackedStrings
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=11, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    net.chunk = 16
+    x = om.synthetic_tiles(48, 3, 32, seed=21).to(DEV)
+    with torch.no_grad():
+        comp = net.compress(x)
+        lst = comp["strings"][0]
+        assert isinstance(lst, PackedStrings) and lst.still_packed()
+        ref = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+        lens = {}
+        pair = None
+        for i, s in enumerate(lst):
+            if len(s) in lens and lst[lens[len(s)]] != s:
+                pair = (lens[len(s)], i)
+                break
+            lens[len(s)] = i
+        assert pair is not None, "no two tiles with equal stream length; enlarge the batch"
+        i, j = pair
+        lst[j] = lst[i]                       # same length, different content, not at a sampled position necessarily
+        assert not lst.still_packed()
+        got = net.decompress(comp["strings"], comp["shape"])["x_hat"]
+        plain = net.decompress([[bytes(s) for s in lst]], comp["shape"])["x_hat"]
+        assert torch.equal(got, plain)
+        assert torch.equal(got[j], ref[i]) and not torch.equal(got[j], ref[j])
+        keep = [k for k in range(48) if k != j]
+        assert torch.equal(got[keep], ref[keep])
+        # deletions / insertions / reversal are caught too
+        c2 = net.compress(x)
+        l2 = c2["strings"][0]
+        l2.reverse()
+        assert not l2.still_packed()
+        assert torch.equal(net.decompress(c2["strings"], c2["shape"])["x_hat"], ref.flip(0))
+        c3 = net.compress(x)
+        del c3["strings"][0][5]
+        assert torch.equal(net.decompress(c3["strings"], c3["shape"])["x_hat"], torch.cat((ref[:5], ref[6:])))
+
+
 @pytest.mark.parametrize("cin,h,w", [(3, 64, 64), (1, 32, 48), (3, 256, 256), (4, 18, 70), (2, 16, 16)])
 def test_first_stage_space_to_depth_equals_conv(cin, h, w):
     """5x5 stride-2 conv over <=4 channels computed as a 3x3 stride-1 conv over the 2x2 space-to-depth image."""

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblicos_hip.so")
+SO_PATH = os.environ.get("LICOS_HIP_SO") or os.path.join(_HERE, "liblicos_hip.so")  # override: A/B builds of dev tools
 
 _c = ctypes
 _vp, _i, _l, _f = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float

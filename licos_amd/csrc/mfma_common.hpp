@@ -76,9 +76,20 @@ __device__ inline void xcd_work_item(int l, int B, int per_image, int &b, int &i
 }
 
 // 16 B global -> LDS without a register round trip: LDS address = wave-uniform base + lane * 16.
-__device__ inline void glds16(const void *gsrc, void *lds_wave_base) {
+// Issued as inline assembly on purpose.  With the builtin (__builtin_amdgcn_global_load_lds) in flight the compiler
+// treats lgkmcnt as unordered and turns every wait in front of an MFMA into s_waitcnt lgkmcnt(0) - also for
+// ds_reads issued two instructions earlier - which defeats reading LDS fragments ahead of their use.  The hardware
+// counts an LDS-DMA in vmcnt only, and every kernel here already orders its LDS reads behind the data with an explicit
+// `s_waitcnt vmcnt(0)` + s_barrier, so nothing depends on the compiler knowing about the transfer.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+#ifdef LICOS_GLDS_BUILTIN  // A/B build only (tools/ab_build.sh): the compiler-visible form
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+  return;
+#endif
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v));  // m0 is a reserved register the compiler only writes right before its own uses
 }
 
 // Transposed conv (mfma_deconv.hip): a workgroup owns ONE output phase (py, px) of a TH x TW input tile.  The
@@ -260,6 +271,7 @@ static inline int mt_for(int Cout) {
 int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
 int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv8.hip; 1 = not applicable
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
+int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_deconv8.hip; 1 = not applicable
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 
 }  // namespace licos

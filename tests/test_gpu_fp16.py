@@ -58,7 +58,11 @@ def test_conv_stage_exact_operands(cin, cout, h, w):
 
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
                                            (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19),
-                                           (128, 7, 9, 40), (192, 24, 8, 33)])
+                                           (128, 7, 9, 40), (192, 24, 8, 33),
+                                           # the 8-wave kernel (input >= 16 x 32, <= 128 output channels): whole and ragged
+                                           # 16 x 32 tiles, the bench geometry, a granule-shaped map, 96 channels
+                                           (128, 128, 40, 80), (128, 128, 18, 35), (128, 96, 16, 32), (192, 128, 17, 64),
+                                           (128, 128, 128, 128), (128, 128, 72, 81)])
 def test_deconv_stage_exact_operands(cin, cout, h, w):
     g = torch.Generator().manual_seed(cin + cout + h)
     x = h16(torch.randn(2, cin, h, w, generator=g))
@@ -73,7 +77,10 @@ def test_deconv_stage_exact_operands(cin, cout, h, w):
     assert rel_err(out, ref) < 2e-5
     if cout > 32:
         outb = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=False)
-        assert rel_err(ops.blk16_to_nchw_f32(outb, cout), ref) < 1e-3
+        gotb = ops.blk16_to_nchw_f32(outb, cout).cpu()
+        assert rel_err(gotb, ref) < 1e-3
+        # element-wise: one fp16 rounding of the fp32 sum (2^-11 relative) plus the summation-order noise of the sum
+        assert bool(((gotb - ref).abs() <= 4.9e-4 * ref.abs() + 2e-5 * float(ref.abs().max())).all())
     outc = ops.deconv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True, clamp01=True)
     assert rel_err(outc, ref.clamp(0, 1)) < 2e-5
     if cout <= 32:  # the all-phase few-channel kernel with compact weights

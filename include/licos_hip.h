@@ -278,7 +278,8 @@ int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch,
 size_t licos_packed_deconv_w_scatter_bytes(int Cin, int Cout);
 int licos_pack_deconv_w_scatter_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scatter, const float *bias, float *y_nchw,
-                                  int clamp01, int B, int Cin, int H, int W, int Cout, void *stream);
+                                  int clamp01 /* bit 0: clamp to [0,1]; bit 1: x is x-split (LICOS_EPI_IN_XSPLIT) */, int B,
+                                  int Cin, int H, int W, int Cout, void *stream);
 
 /* 1x1 convolution on the matrix cores, NCHW fp32 output: the channel product of GDN / IGDN ([CAI] layers/gdn.py:
  * norm = conv2d(x^2, gamma, beta)) and of its backward pass (gamma^T . t), as three split-operand passes (`epilogue` =
@@ -316,6 +317,17 @@ int licos_wgrad5x5s2_f16(const void *small_bm8, const void *large_bm8, float *sc
 /* with LICOS_EPI_ACCUMULATE: y_nchw += 2^-k * result, k = 0..63 - undoes the 2^k by which a residual operand was scaled
  * up before its conversion to fp16 (licos_nchw_f32_split_blk16's lo_shift, the weight residual likewise) */
 #define LICOS_EPI_SCALE_DOWN(k) (((k) & 63) << 12)
+/* OR-ed into licos_deconv5x5s2_f16's `epilogue`: the blk16 input / output is in the x-split form
+ *   [B][C/16][H][2][W/2][16]   (each row as two half rows: its even-x pixels, then its odd-x pixels; W even).
+ * One output phase of a transposed convolution writes every other pixel of a row; x-split, that is one contiguous run
+ * (whole 1-KiB stores, whole cache lines) instead of 32-byte pieces at a 64-byte stride.  Only some kernels take or
+ * produce it: ask licos_deconv5x5s2_f16_layouts() for the stage; the last-stage scatter kernel takes it as input
+ * (bit 1 of its `clamp01` argument). */
+#define LICOS_EPI_IN_XSPLIT 0x200
+#define LICOS_EPI_OUT_XSPLIT 0x400
+/* bit mask (LICOS_EPI_IN_XSPLIT | LICOS_EPI_OUT_XSPLIT or 0) of the layout flags licos_deconv5x5s2_f16 accepts for a
+ * blk16-output stage of this shape (H, W = input size) */
+int licos_deconv5x5s2_f16_layouts(int Cin, int H, int W, int Cout);
 /* x: blk16 [B][Cin16/16][H][W][16]; out: blk16 fp16 (y_blk16) or NCHW fp32 (y_nchw), exactly one non-NULL.
  * Cout_real <= Cout_packed: channels beyond Cout_real are not stored.  H, W are the INPUT size. */
 int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,

@@ -133,6 +133,7 @@ struct MfmaArgs {
   float out_scale;        // 2^-k of LICOS_EPI_SCALE_DOWN(k); 1 otherwise
   int s1conv;             // deconv kernel used as a 3x3 stride-1 conv (space-to-depth first stage): one 'phase', no upsampling
   const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
+  int in_xsplit, out_xsplit;  // LICOS_EPI_IN_XSPLIT / LICOS_EPI_OUT_XSPLIT (mfma_deconv8.hip only)
 };
 
 // ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
@@ -272,6 +273,7 @@ int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_
 int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv8.hip; 1 = not applicable
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_deconv8.hip; 1 = not applicable
+bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv);
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 
 }  // namespace licos

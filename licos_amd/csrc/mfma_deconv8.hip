@@ -22,6 +22,9 @@
 #ifndef LICOS_ABL
 #define LICOS_ABL 0
 #endif
+#ifndef LICOS_STAGGER
+#define LICOS_STAGGER 0
+#endif
 
 namespace licos {
 
@@ -43,9 +46,9 @@ struct Deconv8Geom {
 // one cin chunk of one phase: NKY x NKX taps x MT A fragments, each against the NT pixel tiles of the wave.  The LDS
 // reads run TWO items (one item = one A fragment = NT MFMAs) ahead of their use, pinned by sched_group_barrier: a
 // ds_read_b128 takes longer to come back than the NT MFMAs of one item take to issue.
-template <int MT, int NT, int NKY, int NKX, int RS>
+template <int MT, int NT, int NKY, int NKX, int RS, class Mid>
 __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8 *s_patch, const half8 *s_w,
-                                              const int (&base)[NT], int lane) {
+                                              const int (&base)[NT], int lane, Mid &&mid) {
   constexpr int NTAP = NKY * NKX, NI = NTAP * MT;
   static_assert(MT >= 2, "the B fragments of the next tap are requested two items before its first use");
   // tap t = iky * NKX + ikx reads the patch at (dy, dx) = (1 - iky, 1 - ikx) (see mfma_deconv.hip)
@@ -56,6 +59,7 @@ __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8
     constexpr int it = decltype(itc)::value, mt = it % MT, tap = it / MT;
     constexpr bool more_a = it + 2 < NI, more_b = (mt == MT - 2) && (tap + 1 < NTAP);
     constexpr int iky_n = (tap + 1) / NKX, ikx_n = (tap + 1) % NKX;
+    if (it == NI / 2) mid();  // half-way hook (the younger half of the waves requests its operands here)
     half8 a_nn = a_nxt;
     if (more_a) a_nn = s_w[(it + 2) * 64 + lane];
     if (more_b) {
@@ -81,26 +85,27 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   using G = Deconv8Geom<MT>;
   constexpr int NT = G::NT;
   constexpr bool NORM = (EPI == EPI_GDN || EPI == EPI_IGDN) && LICOS_ABL != 2;
+  constexpr int NSTORE = NT * MT * 2;  // 16-byte store instructions of one epilogue when every row of the wave is live
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half8 *s_pbuf = reinterpret_cast<half8 *>(smem);   // [2][PATCH_PAD]
   half8 *s_wbuf = s_pbuf + 2 * G::PATCH_PAD;         // [2][W_GRAN_MAX]
-  bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(s_wbuf + 2 * G::W_GRAN_MAX);
+  float *s_bias = reinterpret_cast<float *>(s_wbuf + 2 * G::W_GRAN_MAX);  // [32 MT] bias, then [32 MT] beta
+  float *s_beta = s_bias + 32 * MT;
+  bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(s_beta + 32 * MT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  int b, item;
-  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4), b, item);
-  const int phase = a.s1conv ? 0 : (item & 3), tile = a.s1conv ? item : (item >> 2);
-  const int py = phase >> 1, px = phase & 1;
-  const int ntap = (py ? 2 : 3) * (px ? 2 : 3);
-  const int phase_tap0 = (phase == 0) ? 0 : (phase == 1) ? 9 : (phase == 2) ? 15 : 21;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int nphase = a.s1conv ? 1 : 4;
   const int ty0 = (tile / a.tiles_x) * G::TH, tx0 = (tile % a.tiles_x) * G::TW;
 
   const size_t plane = (size_t)a.H * a.W;
   const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
-  // per-lane source offset of this wave's patch pieces inside a chunk plane (-1: outside the image / padding)
+  // per-lane source offset of this wave's patch pieces inside a chunk plane (-1: outside the image / padding); the
+  // same for every phase and chunk
   int p_off[G::NPP];
 #pragma unroll
   for (int i = 0; i < G::NPP; ++i) {
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
     const int j = rem / G::RS, q = rem - j * G::RS;
     const int iy = ty0 - 1 + j, ix = tx0 - 1 + q;
     const bool ok = d < G::PATCH_GRAN && q < G::TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    p_off[i] = ok ? (iy * a.W + ix) * 2 + hh : -1;
+    const int pix = a.in_xsplit ? (iy * 2 + (ix & 1)) * (a.W >> 1) + (ix >> 1) : iy * a.W + ix;
+    p_off[i] = ok ? pix * 2 + hh : -1;
   }
   auto dma_patch = [&](int cc, int buf) {
     const half8 *xin = xb + (size_t)cc * plane * 2;
@@ -119,18 +125,33 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
       if (q < G::PQ) glds16(p_off[i] >= 0 ? xin + p_off[i] : zero, s_pbuf + buf * G::PATCH_PAD + q * 64);
     }
   };
-  const int wq = ntap * MT;  // weight pieces per chunk
-  auto dma_w = [&](int cc, int buf) {
-    const half8 *wsrc = a.wp + ((size_t)phase_tap0 * a.Cin16 + (size_t)cc * ntap) * MT * 64 + lane;
+  auto dma_w = [&](int phase, int cc, int buf) {  // all taps of (phase, cin chunk): ntap * MT pieces
+    const int ntap = ((phase >> 1) ? 2 : 3) * ((phase & 1) ? 2 : 3);
+    const int tap0 = (phase == 0) ? 0 : (phase == 1) ? 9 : (phase == 2) ? 15 : 21;
+    const half8 *wsrc = a.wp + ((size_t)tap0 * a.Cin16 + (size_t)cc * ntap) * MT * 64 + lane;
 #pragma unroll
     for (int i = 0; i < G::NWP; ++i) {
       const int q = wave + 8 * i;
-      if (q < wq) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN_MAX + q * 64);
+      if (q < ntap * MT) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN_MAX + q * 64);
+    }
+  };
+  // operands of K step `cc` of `phase`, or of the first step of the next phase when cc runs past the last chunk
+  auto dma_step = [&](int phase, int cc, int buf) {
+    if (cc >= a.Cin16) {
+      cc -= a.Cin16;
+      ++phase;
+    }
+    if (phase < nphase) {
+      dma_w(phase, cc, buf);
+      dma_patch(cc, buf);
     }
   };
 
-  dma_patch(0, 0);
-  dma_w(0, 0);
+  dma_step(0, 0, 0);
+  // bias and beta live in LDS: a global load after the prologue would be one more vmcnt event whose wait drains the
+  // LDS-DMA requests and the stores in front of it (see the counted wait below)
+  static_assert(MT == 4, "bias + beta = one 64-lane piece");
+  if (wave == 0) glds16((lane < 32 || !NORM) ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias);
   if (NORM) {
 #pragma unroll
     for (int i = 0; i < G::NGP; ++i) {
@@ -139,134 +160,175 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
     }
   }
 
-  int base[NT], oy[NT], ox[NT];
+  int base[NT], oyh[NT], oxh[NT];  // output position of the input pixel at phase (0, 0); row -1 = outside the map
+  bool all_live = a.Cout >= 32 * MT - 15;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int ty = wave * NT + nt, tx = r;
     const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W;
-    oy[nt] = in ? (a.s1conv ? ty0 + ty : 2 * (ty0 + ty) + py) : -1;
-    ox[nt] = a.s1conv ? tx0 + tx : 2 * (tx0 + tx) + px;
+    oyh[nt] = in ? ty0 + ty : -1;
+    oxh[nt] = tx0 + tx;
+    all_live = all_live && (ty0 + ty) < a.H;  // wave-uniform: a live row issues its stores whatever its columns
     base[nt] = h * G::HALF + (ty + 1) * G::RS + (tx + 1);  // patch row 0 / column 0 = input row ty0-1 / column tx0-1
   }
   // accumulators start at the bias: channel of register q in tile mt is 32mt + (q&3) + 8(q>>2) + 4h
   f32x16 acc[MT][NT];
+  auto acc_init = [&]() {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4 *>(a.bias + 32 * mt + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(s_bias + 32 * mt + 8 * g + 4 * h);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[mt][nt][4 * g + 0] = bv.x;
-        acc[mt][nt][4 * g + 1] = bv.y;
-        acc[mt][nt][4 * g + 2] = bv.z;
-        acc[mt][nt][4 * g + 3] = bv.w;
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt][4 * g + 0] = bv.x;
+          acc[mt][nt][4 * g + 1] = bv.y;
+          acc[mt][nt][4 * g + 2] = bv.z;
+          acc[mt][nt][4 * g + 3] = bv.w;
+        }
       }
-    }
+  };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // the whole K loop is instantiated per phase (a switch INSIDE the loop makes the register allocator spill)
-  auto kloop = [&](auto nky_c, auto nkx_c) {
+  acc_init();
+
+  // The workgroup walks the phases of its tile one after the other: ONE stream of K steps (phase, cin chunk), each
+  // step's operands requested one step ahead into the other buffer, with a phase's epilogue between its last step and
+  // the next phase's first.  Stores and LDS-DMA share vmcnt (in issue order), so around an epilogue the order is:
+  //   barrier of the last step | request the operands of the next phase's SECOND step | epilogue arithmetic, stores |
+  //   MFMAs of the next phase's first step | s_waitcnt vmcnt(NSTORE) | barrier
+  // - the counted wait lets the NSTORE youngest operations (the stores) stay in flight and still guarantees the
+  // requests issued before them have landed; the stores are waited for one whole step later, by the vmcnt(0) of the
+  // second step.  Waves that issue fewer stores (rows outside the map, fewer channels) wait for vmcnt(0).
+  int cur = 0;
+  bool requested = false;  // the operands of the coming step's successor are already on their way
+  auto kloop = [&](auto nky_c, auto nkx_c, int phase) {
     constexpr int NKY = decltype(nky_c)::value, NKX = decltype(nkx_c)::value;
     for (int cc = 0; cc < a.Cin16; ++cc) {
-      const int cur = cc & 1;
-      if (cc + 1 < a.Cin16 && LICOS_ABL != 1) {  // the next chunk's operands land while this chunk's MFMAs run
-        dma_w(cc + 1, cur ^ 1);
-        dma_patch(cc + 1, cur ^ 1);
-      }
+      const bool counted = requested && all_live;
+      // waves 0-3 request the next step's operands at the start of the step, waves 4-7 (their SIMD partners) half-way
+      // through it: a request costs its wave ~60 issue cycles per piece, which the partner's MFMAs cover only if the
+      // two are not doing it at the same moment
+      const bool want = !requested && LICOS_ABL != 1;
+      const bool late = LICOS_STAGGER && wave >= 4;
+      if (want && !late) dma_step(phase, cc + 1, cur ^ 1);
+      requested = false;
       if (LICOS_ABL != 4)
-        deconv8_chunk<MT, NT, NKY, NKX, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_wbuf + cur * G::W_GRAN_MAX, base, lane);
+        deconv8_chunk<MT, NT, NKY, NKX, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_wbuf + cur * G::W_GRAN_MAX, base, lane,
+                                               [&]() { if (want && late) dma_step(phase, cc + 1, cur ^ 1); });
+      else if (want && late) dma_step(phase, cc + 1, cur ^ 1);
       // my DMA pieces have landed; after the barrier so have everyone's, and every wave is done reading the buffers
       // the next step overwrites
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      cur ^= 1;
     }
   };
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
-  switch (phase) {  // wave-uniform
-    case 0: kloop(I3{}, I3{}); break;
-    case 1: kloop(I3{}, I2{}); break;
-    case 2: kloop(I2{}, I3{}); break;
-    default: kloop(I2{}, I2{}); break;
-  }
-
-  // ---- epilogue: (I)GDN per pixel tile, fp16 pack, 16-byte stores --------------------------------------------
   const int Cout16 = (a.Cout + 15) >> 4;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    bf16x8 sq[MT][2];
-    if (NORM) {
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = acc[jt][nt][8 * s + e];
-            sq[jt][s][e] = (__bf16)(v * v);
-          }
+
+  // straight-line code per phase (a loop over phases with a switch makes the register allocator spill)
+  auto run_phase = [&](auto nky_c, auto nkx_c, auto phase_c) {
+    constexpr int phase = decltype(phase_c)::value;
+    kloop(nky_c, nkx_c, phase);
+    if (phase + 1 < nphase && a.Cin16 > 1 && LICOS_ABL != 1) {
+      dma_step(phase + 1, 1, cur ^ 1);
+      requested = true;
     }
-    const bool live = oy[nt] >= 0 && oy[nt] < a.Ho && ox[nt] < a.Wo;
+    asm volatile("" ::: "memory");  // the stores below stay behind the requests above (see the counted wait)
+
+    // ---- epilogue: (I)GDN per pixel tile, fp16 pack, 16-byte stores ------------------------------------------
+    constexpr int py = phase >> 1, px = phase & 1;
 #pragma unroll
-    for (int it = 0; it < MT; ++it) {
-      f32x16 scale;
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 sq[MT][2];
       if (NORM) {
-        f32x16 norm;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 bv = *reinterpret_cast<const float4 *>(a.beta + 32 * it + 8 * g + 4 * h);
-          norm[4 * g + 0] = bv.x;
-          norm[4 * g + 1] = bv.y;
-          norm[4 * g + 2] = bv.z;
-          norm[4 * g + 3] = bv.w;
-        }
 #pragma unroll
         for (int jt = 0; jt < MT; ++jt)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            norm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_gamma[((it * MT + jt) * 2 + s) * 64 + lane], sq[jt][s], norm, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          scale[q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[q]) : __builtin_amdgcn_sqrtf(norm[q]);
+            for (int e = 0; e < 8; ++e) {
+              const float v = acc[jt][nt][8 * s + e];
+              sq[jt][s][e] = (__bf16)(v * v);
+            }
       }
-      // a lane holds channels {0-3, 8-11} (+4 for the upper half-wave) of each 16-channel chunk; one
-      // v_permlane32_swap per dword hands the lower lane channels 0-7 and the upper lane 8-15: one 16-byte store each
+      const int oy = a.s1conv ? oyh[nt] : 2 * oyh[nt] + py, ox = a.s1conv ? oxh[nt] : 2 * oxh[nt] + px;
+      const bool live = oyh[nt] >= 0 && oy < a.Ho && ox < a.Wo;
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        unsigned lo[2], hi[2];
+      for (int it = 0; it < MT; ++it) {
+        f32x16 scale;
+        if (NORM) {
+          f32x16 norm;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          float v0[2], v1[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            v0[e] = acc[it][nt][8 * gp + 2 * d + e];
-            v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
-            if (NORM) {
-              v0[e] *= scale[8 * gp + 2 * d + e];
-              v1[e] *= scale[8 * gp + 4 + 2 * d + e];
-            }
-            if (EPI == EPI_RELU) {
-              v0[e] = fmaxf(v0[e], 0.f);
-              v1[e] = fmaxf(v1[e], 0.f);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(s_beta + 32 * it + 8 * g + 4 * h);
+            norm[4 * g + 0] = bv.x;
+            norm[4 * g + 1] = bv.y;
+            norm[4 * g + 2] = bv.z;
+            norm[4 * g + 3] = bv.w;
           }
-          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-          half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
-          lo[d] = __builtin_bit_cast(unsigned, p0);
-          hi[d] = __builtin_bit_cast(unsigned, p1);
-          const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
-          lo[d] = sw[0];
-          hi[d] = sw[1];
+#pragma unroll
+          for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              norm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_gamma[((it * MT + jt) * 2 + s) * 64 + lane], sq[jt][s], norm, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            scale[q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[q]) : __builtin_amdgcn_sqrtf(norm[q]);
         }
-        const int chunk = 2 * it + gp;
-        if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
-          _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + chunk) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + 8 * h;
-          *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+        // a lane holds channels {0-3, 8-11} (+4 for the upper half-wave) of each 16-channel chunk; one
+        // v_permlane32_swap per dword hands the lower lane channels 0-7 and the upper lane 8-15: one 16-byte store each
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          unsigned lo[2], hi[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            float v0[2], v1[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              v0[e] = acc[it][nt][8 * gp + 2 * d + e];
+              v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
+              if (NORM) {
+                v0[e] *= scale[8 * gp + 2 * d + e];
+                v1[e] *= scale[8 * gp + 4 + 2 * d + e];
+              }
+              if (EPI == EPI_RELU) {
+                v0[e] = fmaxf(v0[e], 0.f);
+                v1[e] = fmaxf(v1[e], 0.f);
+              }
+            }
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
+            lo[d] = __builtin_bit_cast(unsigned, p0);
+            hi[d] = __builtin_bit_cast(unsigned, p1);
+            const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+            lo[d] = sw[0];
+            hi[d] = sw[1];
+          }
+          const int chunk = 2 * it + gp;
+          if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
+            // x-split output: row oy as [even-x pixels][odd-x pixels] - this phase's pixels of the row are one run
+            const size_t pix = a.out_xsplit ? ((size_t)oy * 2 + px) * a.W + oxh[nt] : (size_t)oy * a.Wo + ox;
+            _Float16 *dst = a.y_blk + (((size_t)b * Cout16 + chunk) * a.Ho * a.Wo + pix) * 16 + 8 * h;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+          }
         }
+        // one 32-channel tile at a time: letting the scheduler interleave the four norm chains costs 48 more live
+        // registers than the kernel has, and a spill reload is a vmcnt event (see above)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (phase + 1 < nphase) acc_init();
+  };
+  run_phase(I3{}, I3{}, std::integral_constant<int, 0>{});
+  if (nphase > 1) {
+    run_phase(I3{}, I2{}, std::integral_constant<int, 1>{});
+    run_phase(I2{}, I3{}, std::integral_constant<int, 2>{});
+    run_phase(I2{}, I2{}, std::integral_constant<int, 3>{});
   }
 }
 
@@ -276,14 +338,14 @@ static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.W, G::TW);
   a.tiles_y = cdiv(a.H, G::TH);
-  const size_t lds = (size_t)16 * (G::KLOOP_GRAN + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
+  const size_t lds = (size_t)16 * (G::KLOOP_GRAN + 16 * MT + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
   auto kern = deconv5x5s2_mfma8_kernel<MT, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const long blocks = (long)a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4) * a.B;
+  const long blocks = (long)a.tiles_x * a.tiles_y * a.B;  // a workgroup walks all four phases of its tile
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
   LICOS_LAUNCH_CHECK();
@@ -291,9 +353,13 @@ static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
 }
 
 // returns LICOS_OK after launching, or 1 when this variant does not apply (caller falls back to the 4-wave kernel)
-int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
+bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv) {
   static const bool enabled = [] { const char *e = getenv("LICOS_DECONV8"); return !(e && e[0] == '0'); }();
-  if (!enabled || MT != 4 || a.H < 16 || a.W < 32 || !a.y_blk || a.accum) return 1;
+  return enabled && MT == 4 && H >= 16 && W >= 32 && blk_out && !accum && (Cin16 >= 2 || s1conv);
+}
+
+int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
+  if (!mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, a.y_blk != nullptr, a.accum != 0, a.s1conv != 0)) return 1;
   if (epi == EPI_IGDN) return launch_deconv8<4, EPI_IGDN>(a, s);
   if (epi == EPI_GDN) return launch_deconv8<4, EPI_GDN>(a, s);
   if (epi == EPI_NONE) return launch_deconv8<4, EPI_NONE>(a, s);

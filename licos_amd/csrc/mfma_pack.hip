@@ -392,6 +392,7 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   a.accum = accum;
   a.out_scale = ldexpf(1.f, -down);
   a.s1conv = 0;
+  a.in_xsplit = a.out_xsplit = 0;
   a.zero16 = zero_page();
   LICOS_REQUIRE(a.zero16 != nullptr, "%s: could not allocate the zero page", who);
   *MT_out = MT;
@@ -420,7 +421,20 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
   a.Ho = 2 * H;
   a.Wo = 2 * W;
   a.clamp01 = clamp01;
+  a.in_xsplit = (epilogue & LICOS_EPI_IN_XSPLIT) ? 1 : 0;
+  a.out_xsplit = (epilogue & LICOS_EPI_OUT_XSPLIT) ? 1 : 0;
+  if (a.in_xsplit || a.out_xsplit) {
+    LICOS_REQUIRE(mfma_deconv8_applies(MT, a.Cin16, H, W, y_blk16 != nullptr, a.accum != 0, false),
+                  "deconv5x5s2_f16: the x-split layout is not available for this stage (see licos_deconv5x5s2_f16_layouts)");
+    LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_f16: x-split input needs an even width");
+  }
   return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W, as_stream(stream));
+}
+
+int licos_deconv5x5s2_f16_layouts(int Cin, int H, int W, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  if (!mfma_deconv8_applies(mt_for(Cout), (Cin + 15) / 16, H, W, true, false, false)) return 0;
+  return LICOS_EPI_OUT_XSPLIT | (W % 2 == 0 ? LICOS_EPI_IN_XSPLIT : 0);
 }
 
 }  // extern "C"

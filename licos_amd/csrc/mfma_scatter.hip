@@ -19,7 +19,7 @@ struct ScatterArgs {
   const half8 *wp;    // [Cout][Cin16][64 lanes] A fragments: row = tap (25 live), k = channel within the chunk
   const float *bias;  // [Cout]
   float *y;           // NCHW fp32 [B][Cout][2H][2W]
-  int B, Cin16, H, W, Cout, tiles_x, tiles_y, clamp01;
+  int B, Cin16, H, W, Cout, tiles_x, tiles_y, clamp01, in_xsplit;
 };
 
 constexpr int SC_TH = 8, SC_TW = 32, SC_PW = SC_TW + 2, SC_NPX = (SC_TH + 2) * SC_PW;  // 340 patch pixels
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_scatter_kernel(ScatterArgs
     const int prow = p / SC_PW, pcol = p - prow * SC_PW;
     const int iy = ty0 - 1 + prow, ix = tx0 - 1 + pcol;
     const bool ok = p < SC_NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    src_off[nt] = ok ? (iy * a.W + ix) * 2 + h : -1;
+    const int pix = a.in_xsplit ? (iy * 2 + (ix & 1)) * (a.W >> 1) + (ix >> 1) : iy * a.W + ix;
+    src_off[nt] = ok ? pix * 2 + h : -1;
     oyb[nt] = 2 * (prow - 1) - 2;  // output row (tile-local) of tap ky = 0
     oxb[nt] = 2 * (pcol - 1) - 2;
   }
@@ -183,7 +184,9 @@ int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scat
   a.Cout = Cout;
   a.tiles_x = cdiv(W, SC_TW);
   a.tiles_y = cdiv(H, SC_TH);
-  a.clamp01 = clamp01;
+  a.clamp01 = clamp01 & 1;
+  a.in_xsplit = (clamp01 >> 1) & 1;
+  LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_scatter_f16: x-split input needs an even width");
   hipStream_t s = as_stream(stream);
   switch (Cout) {
     case 1: return launch_scatter<1>(a, s);

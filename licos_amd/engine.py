@@ -125,16 +125,35 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
     else:
         cur = x_blk
+    xsplit = False  # layout of `cur`: blk16, or its x-split form (ops.EPI_OUT_XSPLIT) between two kernels that agree on it
+
+    def scatter_last(i):
+        m, g = st[i]
+        return (i == len(st) - 1 and isinstance(m, nn.ConvTranspose2d) and g is None and SCATTER_LAST
+                and m.out_channels <= 4 and m.in_channels in (128, 192))
+
+    def takes_xsplit(i, h, w):
+        """Does stage i, fed an h x w map, read the x-split layout?"""
+        if i >= len(st) or w % 2:
+            return False
+        m, g = st[i]
+        if not isinstance(m, nn.ConvTranspose2d):
+            return False
+        if scatter_last(i):
+            return True
+        return i < len(st) - 1 and bool(ops.deconv_layouts(m.in_channels, h, w, m.out_channels) & ops.EPI_IN_XSPLIT)
+
     for idx, (m, g) in enumerate(st):
         last = idx == len(st) - 1
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
-        if fewch and SCATTER_LAST and m.out_channels <= 4 and m.in_channels in (128, 192):
+        if scatter_last(idx):
             fewch = "scatter"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
         if fewch == "scatter":
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.deconv5x5s2_scatter_f16(cur, wp, bp, m.in_channels, m.out_channels,
-                                                                  clamp01=clamp01, out=out))
+                                                                  clamp01=clamp01, out=out, in_xsplit=xsplit))
+            xsplit = False  # NCHW fp32 from here
             continue
         if fewch:
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
@@ -153,12 +172,22 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
             cur = _timed(key, lambda: ops.conv3x3s1_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))
         elif isinstance(m, nn.ConvTranspose2d):
-            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
-            cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
+            hh, ww = cur.shape[2], cur.shape[3]
+            key = ("deconv", m.in_channels, m.out_channels, hh, ww, cur.shape[0])
+            # one output phase = every other pixel of a row: hand the next kernel the x-split layout when both sides
+            # speak it (whole-line stores here, nothing lost there: LDS-DMA addresses are per lane anyway)
+            flags = ops.EPI_IN_XSPLIT if xsplit else 0
+            out_split = (not last and bool(ops.deconv_layouts(m.in_channels, hh, ww, m.out_channels) & ops.EPI_OUT_XSPLIT)
+                         and takes_xsplit(idx + 1, 2 * hh, 2 * ww))
+            if out_split:
+                flags |= ops.EPI_OUT_XSPLIT
+            cur = _timed(key, lambda: ops.deconv5x5s2_f16(cur, wp, bp, gp, epi | flags, m.in_channels, m.out_channels,
                                                           out_nchw=last, clamp01=clamp01 and last,
                                                           out=out if last else None))
+            xsplit = out_split
         else:
             key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))
+    assert not xsplit, "a transform chain must not end in the x-split layout"
     return cur

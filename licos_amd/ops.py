@@ -494,6 +494,20 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
 # ----------------------------------------------------------------------------- 16-bit MFMA path
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_RELU = 0, 1, 2, 3
 EPI_ACCUMULATE = 0x100  # licos_hip.h LICOS_EPI_ACCUMULATE
+EPI_IN_XSPLIT, EPI_OUT_XSPLIT = 0x200, 0x400  # licos_hip.h: blk16 rows stored as [even-x pixels][odd-x pixels]
+
+
+def deconv_layouts(cin, h, w, cout):
+    """Layout flags (EPI_IN_XSPLIT | EPI_OUT_XSPLIT or 0) the transposed-conv stage of this shape accepts."""
+    return int(_lib.load().licos_deconv5x5s2_f16_layouts(int(cin), int(h), int(w), int(cout)))
+
+
+def blk16_xsplit(x_blk, inverse=False):
+    """blk16 [B][C16][H][W][16] <-> its x-split form (same shape, rows re-ordered); host-side helper for tests / tools."""
+    b, c16, h, w, k = x_blk.shape
+    if inverse:
+        return x_blk.reshape(b, c16, h, 2, w // 2, k).permute(0, 1, 2, 4, 3, 5).reshape(b, c16, h, w, k).contiguous()
+    return x_blk.reshape(b, c16, h, w // 2, 2, k).permute(0, 1, 2, 4, 3, 5).reshape(b, c16, h, w, k).contiguous()
 
 
 def mfma_tiles(cout):
@@ -681,14 +695,14 @@ def pack_deconv_w_scatter_f16(w):
     return packed
 
 
-def deconv5x5s2_scatter_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=None):
+def deconv5x5s2_scatter_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=None, in_xsplit=False):
     _dev(x_blk, w_packed, bias, out)
     b, c16, h, w, _ = x_blk.shape
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("deconv5x5s2_scatter_f16: input is not the blk16 fp16 layout of `cin` channels")
     y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
-    rc = _lib.load().licos_deconv5x5s2_scatter_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(clamp01), b, cin, h, w, cout,
-                                                   _stream())
+    rc = _lib.load().licos_deconv5x5s2_scatter_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
+                                                   b, cin, h, w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_scatter_f16")
     return y
 

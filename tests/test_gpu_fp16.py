@@ -91,6 +91,54 @@ def test_deconv_stage_exact_operands(cin, cout, h, w):
         assert rel_err(outf, ref.clamp(0, 1)) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,h,w,epi", [(128, 128, 32, 32, "igdn"), (128, 128, 40, 80, "none"), (192, 96, 18, 34, "relu"),
+                                               (128, 128, 64, 64, "igdn")])
+def test_deconv_xsplit_layouts_are_bit_exact(cin, cout, h, w, epi):
+    """The x-split activation layout (rows as [even-x pixels][odd-x pixels], LICOS_EPI_IN/OUT_XSPLIT) is a pure
+    re-ordering: every combination of input / output layout gives bit for bit the values of the plain blk16 call, in
+    the 8-wave transposed-conv kernel and in the scatter-form last stage."""
+    from licos_amd import engine
+    from licos_amd.layers import GDN
+    g = torch.Generator().manual_seed(cin + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cin, cout, 5, 5, generator=g) * 0.04)
+    b = torch.randn(cout, generator=g)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV), transposed=True)
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    gp, e = None, ops.EPI_NONE
+    if epi == "igdn":
+        m = GDN(cout, inverse=True).to(DEV)
+        with torch.no_grad():
+            m.gamma.add_((0.02 * torch.rand(cout, cout, generator=g)).to(DEV))
+        gp, e = engine._packed_gdn(m), ops.EPI_IGDN
+    elif epi == "relu":
+        e = ops.EPI_RELU
+    lay = ops.deconv_layouts(cin, h, w, cout)
+    assert lay == (ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT)
+    ref = ops.deconv5x5s2_f16(xb, wp, bp, gp, e, cin, cout)
+    xs = ops.blk16_xsplit(xb)
+    assert not torch.equal(xs, xb)
+    o1 = ops.deconv5x5s2_f16(xb, wp, bp, gp, e | ops.EPI_OUT_XSPLIT, cin, cout)
+    o2 = ops.deconv5x5s2_f16(xs, wp, bp, gp, e | ops.EPI_IN_XSPLIT, cin, cout)
+    o3 = ops.deconv5x5s2_f16(xs, wp, bp, gp, e | ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT, cin, cout)
+    assert torch.equal(ops.blk16_xsplit(o1, inverse=True), ref)
+    assert torch.equal(o2, ref)
+    assert torch.equal(o3, o1)
+    if cin in (128, 192):  # scatter-form last stage reading the x-split layout
+        w3 = h16(torch.randn(cin, 3, 5, 5, generator=g) * 0.04)
+        ws = ops.pack_deconv_w_scatter_f16(w3.to(DEV))
+        b3 = torch.randn(3, generator=g).to(DEV)
+        assert torch.equal(ops.deconv5x5s2_scatter_f16(xs, ws, b3, cin, 3, in_xsplit=True),
+                           ops.deconv5x5s2_scatter_f16(xb, ws, b3, cin, 3))
+    # stages that have no x-split form say so, and the flags are refused there
+    assert ops.deconv_layouts(192, 16, 16, 128) == 0 and ops.deconv_layouts(128, 64, 64, 192) == 0
+    small = torch.zeros(1, 12, 16, 16, 16, device=DEV, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        ops.deconv5x5s2_f16(small, ops.pack_conv_w_f16(torch.zeros(192, 128, 5, 5, device=DEV), transposed=True),
+                            ops.pad_bias(torch.zeros(128, device=DEV), 128, DEV), None, ops.EPI_NONE | ops.EPI_OUT_XSPLIT, 192, 128)
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 32, 32), (128, 1, 16, 16), (128, 3, 128, 128), (128, 2, 9, 40), (128, 4, 20, 36),
                                            (192, 3, 8, 33), (192, 1, 5, 3), (128, 3, 1, 1)])
 def test_scatter_deconv_exact_operands(cin, cout, h, w):

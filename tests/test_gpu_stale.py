@@ -113,15 +113,16 @@ def test_scaled_flat_state_is_seen_by_the_next_forward():
     fs = federation.FlatState(net)
     x0b = _check_against_oracle(net, x)         # re-homing changes storage, not values
     assert rel_err(x0b, x0) < 1e-6
-    ops.scale_f32(fs.flat, 2.0)                 # every float of the state doubled in place, behind torch's back
+    gain = 1.25  # (2.0 drives this random model's g_s beyond fp16 range, where the split-operand fp32 path does not go)
+    ops.scale_f32(fs.flat, gain)                   # every float of the state scaled in place, behind torch's back
     for k, off, n in fs.keys:                   # constants of the model definition (bounds, pedestals, EB target) are
         if k.endswith(("bound", "pedestal", "target")):  # not weights: put them back through the same raw-write kernel
-            ops.scale_f32(fs.flat[off:off + n], 0.5)
+            ops.scale_f32(fs.flat[off:off + n], 1.0 / gain)
     doubled = _cpu_state(net)
-    assert torch.allclose(doubled["g_a.2.weight"], 2 * sd["g_a.2.weight"])
+    assert torch.allclose(doubled["g_a.2.weight"], gain * sd["g_a.2.weight"])
     assert torch.equal(doubled["g_a.1.beta_reparam.pedestal"], sd["g_a.1.beta_reparam.pedestal"])
     x1 = _check_against_oracle(net, x)
-    assert rel_err(x1, x0) > 1e-2
+    assert bool(torch.isfinite(x1).all()) and rel_err(x1, x0) > 1e-2
 
 
 def _free_port():

@@ -9,8 +9,10 @@ hw = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-seq = nn.Sequential(deconv(128, 128), GDN(128, inverse=True), deconv(128, 128)).to(dev).eval()
-x = torch.randn(B, 8, hw, hw, 16, device=dev).half()
+# the probed stage sits between a producer and a consumer of its own kind, as in g_s (x-split layouts on both sides)
+seq = nn.Sequential(deconv(128, 128), GDN(128, inverse=True), deconv(128, 128), GDN(128, inverse=True),
+                    deconv(128, 3)).to(dev).eval()
+x = torch.randn(B, 8, hw // 2, hw // 2, 16, device=dev).half()
 with torch.no_grad():
     for it in range(2 + reps):
         if it == 2:

@@ -1,24 +1,78 @@
 """Headline benchmark: 256x256 tiles/s, encode + decode (BASELINE.json metric), on N MI355X.
 
-One step = compress(x) -> byte strings -> decompress(strings) for one batch of B synthetic
-3x256x256 tiles per GPU that are already resident in HBM (BASELINE.json configs[1]:
-bmshj2018_factorized q=3, 3 channels, fp16 MFMA path).  Tiles shard across ranks with no
-data-path collective (weak scaling: B tiles per GPU).  Rank 0 prints ONE JSON line.
+One step = compress(x) -> byte strings -> decompress(strings) for one batch of B synthetic 3x256x256 tiles per GPU
+that are already resident in HBM (BASELINE.json configs[1]: bmshj2018_factorized q=3, 3 channels, fp16 MFMA path).
+Tiles shard across ranks with no data-path collective (weak scaling: B tiles per GPU).  Rank 0 prints ONE JSON line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Invoked bare with --gpus N > 1 (no WORLD_SIZE in the environment) the process never touches the GPU: it starts N fresh
+worker processes of itself (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's line and
+exits with the workers' status.
+
+Besides the headline the N = 1 line carries (SURVEY.md section 8(d) grid; all timed AFTER the headline region):
+  batches            encode+decode ms and tiles/s at B = 1, 16, 64, 1024 (reference batch sizes: eval B = 1,
+                     cfg/raw_merged.toml batch_size 16, test_batch_size 64)
+  whole_granule      one 1 x 2304 x 2592 band image (eval_script.py's call): as ONE stream, and tiled to 256x256
+  decode_from_plain_bytes   the headline decode fed a plain list[bytes] (re-join + staging) instead of PackedStrings
+  configs            1-channel (raw split) and 13-channel (raw merged) models, fp32 parity path
+  train_step         cfg/raw_merged.toml's step: 16 patches of 13 x 256 x 256, forward + RD loss + backward + clip + Adam x2
+  cpu_baseline       the oracle on this host: 1 thread and all share threads, B = 1 and 16, encode / decode split
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_TILE_A3 = 2 * 1677721600  # g_a[2]: 128->128 5x5 s2 at 128^2 -> 64^2
+FLOP_PER_TILE_A3 = 2 * 1677721600  # g_a[2] = g_s[4]: 128->128 5x5 s2 between 128^2 and 64^2
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16 MFMA (MI355X_MICROARCH.md chip table)
+XGMI_PEAK_GBPS = 7 * 153.0         # per GPU: 7 links x ~153 GB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16384, help="tiles per GPU per step")
+    ap.add_argument("--chunk", type=int, default=4096, help="tiles per pipeline chunk inside a step")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--quality", type=int, default=3)
+    ap.add_argument("--model", default="bmshj2018-factorized", help="zoo name (secondary configs: bmshj2018-hyperprior)")
+    ap.add_argument("--size", type=int, default=256, help="tile edge (BASELINE configs[4] uses 512)")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--weights", default="trained", choices=["trained", "synthetic"],
+                    help="trained: licos_amd/weights (the repo's own training recipe, tools/train_weights.py) when present")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (skip the measurement grid)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    return ap.parse_args()
+
+
+def spawn_workers(args):
+    """--gpus N without a launcher: N fresh worker processes, started BEFORE anything here touches the GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def stage_flops(kind, cin, cout, h, w):
@@ -44,38 +98,161 @@ def quality_match(net, sd, x8):
             "psnr_oracle": round(om.compute_psnr(ref["x_hat"].clamp(0, 1), x8.cpu()), 4)}
 
 
-def cpu_baseline(sd, cin, batch, reps):
-    """The oracle (torch-CPU conv = the reference's CPU arithmetic; restated EB; C rANS) timed on
-    this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(sd, cin, budget_s=24.0):
+    """The oracle (torch-CPU conv = the reference's CPU arithmetic; restated EB; C rANS) timed on this host's cores on
+    a bounded sample of the same workload: threads in {1, share}, B in {1, 16}, encode and decode separately."""
     import torch
     from oracle import model as om
-    threads = min(os.cpu_count() or 1, 16)  # the GPU box gives one GPU a 16-core share; more threads only thrash
-    torch.set_num_threads(threads)
-    x = om.synthetic_tiles(batch, cin, 256, seed=0)
-    om.compress(x[:2], sd)  # warm-up
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    share = max(1, min(share, 16))  # a GPU box gives one GPU a 16-core share; more threads only thrash
+    x = om.synthetic_tiles(16, cin, 256, seed=0)
+    torch.set_num_threads(share)
+    om.decompress(**{k: v for k, v in om.compress(x[:1], sd).items() if k in ("strings", "shape")}, sd=sd)  # warm-up
+    grid, t_start = {}, time.perf_counter()
+    for threads in sorted({1, share}, reverse=True):
+        torch.set_num_threads(threads)
+        for b in (16, 1):
+            enc = dec = 0.0
+            reps = 0
+            while reps < (3 if threads > 1 else 1) and (time.perf_counter() - t_start) < budget_s:
+                t0 = time.perf_counter()
+                c = om.compress(x[:b], sd)
+                t1 = time.perf_counter()
+                om.decompress(c["strings"], c["shape"], sd)
+                t2 = time.perf_counter()
+                enc, dec, reps = enc + (t1 - t0), dec + (t2 - t1), reps + 1
+            if reps:
+                grid["threads%d_B%d" % (threads, b)] = {
+                    "encode_tiles_s": round(b * reps / enc, 2), "decode_tiles_s": round(b * reps / dec, 2),
+                    "tiles_s": round(b * reps / (enc + dec), 2), "reps": reps}
+    torch.set_num_threads(share)
+    best = grid.get("threads%d_B16" % share) or max(grid.values(), key=lambda g: g["tiles_s"])
+    return best["tiles_s"], time.perf_counter() - t_start, share, grid
+
+
+def timed_codec(net, x, reps, plain=False, split=False):
+    """Median wall time (ms) of compress(x) + decompress(...) over `reps` runs, device-synchronised."""
+    import torch
+    enc_t, dec_t = [], []
+    with torch.no_grad():
+        for i in range(reps + 1):  # first run untimed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c = net.compress(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            strings = [[bytes(s) for s in lst] for lst in c["strings"]] if plain else c["strings"]
+            t1b = time.perf_counter()
+            d = net.decompress(strings, c["shape"])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if i:
+                enc_t.append(1e3 * (t1 - t0))
+                dec_t.append(1e3 * (t2 - t1b))
+    enc_t.sort()
+    dec_t.sort()
+    e, dd = enc_t[len(enc_t) // 2], dec_t[len(dec_t) // 2]
+    res = {"ms": round(e + dd, 3), "tiles_s": round(1e3 * x.shape[0] / (e + dd), 1)}
+    if split:
+        res.update(encode_ms=round(e, 3), decode_ms=round(dd, 3))
+    return res, c, d
+
+
+def extras(args, net, x, dev):
+    """The SURVEY 8(d) grid at N = 1 (everything here runs after the timed headline region)."""
+    import torch
+    import licos_amd
+    from licos_amd import synthetic, tiling
+    out = {}
+    # batch sizes of the reference: eval B = 1, training 16, test 64; plus 1024
+    out["batches"] = {}
+    for b in (1, 16, 64, 1024):
+        if b <= x.shape[0]:
+            out["batches"]["B%d" % b] = timed_codec(net, x[:b].contiguous(), 5 if b >= 1024 else 9, split=True)[0]
+    # the headline decode fed a plain list[bytes] (no PackedStrings shortcut)
+    hb = min(x.shape[0], args.batch)
+    packed, _, _ = timed_codec(net, x[:hb], 2, split=True)
+    plain, _, _ = timed_codec(net, x[:hb], 2, plain=True, split=True)
+    out["decode_from_plain_bytes"] = {"tiles": hb, "packed": packed, "plain_list": plain}
+    # fp32 parity path (3-pass split-operand MFMA convolutions, fp32 GDN / EB)
+    if args.precision == "fp16":
+        net.set_precision("fp32")
+        out["fp32_path"] = dict(timed_codec(net, x[:256].contiguous(), 3)[0], tiles=256)
+        net.set_precision("fp16")
+    # 1-channel (raw split) and 13-channel (raw merged) models, and one whole granule as the reference feeds it
+    configs = {}
+    for cin, kind, b in ((1, "s2", 4096), (13, "s2-merged", 2048)):
+        torch.manual_seed(42)
+        n2 = licos_amd.get_model("bmshj2018-factorized", False, cin, args.quality).to(dev).eval().set_precision("fp16")
+        n2.chunk = args.chunk
+        with torch.no_grad():
+            synthetic.make_trained_like(n2, seed=0)
+        xb = synthetic.tiles(b, cin, 256, seed=7, kind=kind, device=dev)
+        configs["%dch" % cin] = dict(timed_codec(n2, xb, 3)[0], tiles=b)
+        if cin == 1:
+            g = synthetic.tiles(1, 1, 2592, seed=11, kind="s2", device=dev)[:, :, :2304, :].contiguous()  # raw_utils.py:131
+            one, c, d = timed_codec(n2, g, 3, split=True)  # eval_script.py:138-165: ONE image, one rANS stream of 4.5 M symbols
+            one["bytes"] = sum(len(s) for s in c["strings"][0])
+            with torch.no_grad():
+                ts = []
+                for i in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    coded = tiling.compress_image(n2, g)
+                    dec = tiling.decompress_image(n2, coded)
+                    torch.cuda.synchronize()
+                    ts.append(1e3 * (time.perf_counter() - t0))
+            ts = sorted(ts[1:])
+            out["whole_granule_1x2304x2592"] = {
+                "one_stream": one, "tiled_256": {"ms": round(ts[len(ts) // 2], 3), "tiles": len(coded["strings"][0]),
+                                                 "bytes": sum(len(s) for s in coded["strings"][0])}}
+        del n2, xb
+    out["configs"] = configs
+    out["train_step"] = train_step_ms(dev, steps=10)[0]
+    return out
+
+
+def train_step_ms(dev, steps=10, world=1):
+    """cfg/raw_merged.toml's training step on the device (HIP forward and backward, fp32): licos/train.py:186-200."""
+    import torch
+    import licos_amd
+    from licos_amd import synthetic
+    torch.manual_seed(42)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1).to(dev).train()
+    crit = licos_amd.RateDistortionLoss(lmbda=1e-2)
+    opt = licos_amd.net_aux_optimizer(net, {"net": {"type": "Adam", "lr": 1e-4}, "aux": {"type": "Adam", "lr": 1e-3}})
+    x = synthetic.tiles(16, 13, 256, seed=1, kind="s2-merged", device=dev)
+
+    def step():
+        opt["net"].zero_grad()
+        opt["aux"].zero_grad()
+        res = crit(net(x), x)
+        res["loss"].backward()
+        licos_amd.optimizers.clip_grad_norm_(list(net.parameters()), 1.0, opt["net"])
+        opt["net"].step()
+        net.aux_loss().backward()
+        opt["aux"].step()
+        return res
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        c = om.compress(x, sd)
-        om.decompress(c["strings"], c["shape"], sd)
-    dt = time.perf_counter() - t0
-    return batch * reps / dt, dt, threads
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"ms": round(ms, 3), "patches_s": round(16e3 / ms, 1), "loss": round(float(res["loss"]), 4),
+            "what": "16 x 13x256x256 patches: forward (noise) + RD loss + backward + clip 1.0 + Adam 1e-4 / aux Adam 1e-3"}, net
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="tiles per GPU per step")
-    ap.add_argument("--chunk", type=int, default=4096, help="tiles per pipeline chunk inside a step")
-    ap.add_argument("--channels", type=int, default=3)
-    ap.add_argument("--quality", type=int, default=3)
-    ap.add_argument("--model", default="bmshj2018-factorized", help="zoo name (secondary configs: bmshj2018-hyperprior)")
-    ap.add_argument("--size", type=int, default=256, help="tile edge (BASELINE configs[4] uses 512)")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_workers(args))
 
     import torch
     import torch.distributed as dist
@@ -106,8 +283,15 @@ def main():
     net = licos_amd.get_model(args.model, False, args.channels, args.quality)
     net = net.to(dev).eval().set_precision(args.precision)
     net.chunk = args.chunk
-    with torch.no_grad():
-        synthetic.make_trained_like(net, seed=0)
+    weights = "synthetic trained-like (seeded)"
+    wfile = os.path.join(ROOT, "licos_amd", "weights", "factorized_q%d_c%d.pth.tar" % (args.quality, args.channels))
+    if args.weights == "trained" and args.model == "bmshj2018-factorized" and os.path.exists(wfile):
+        from licos_amd import checkpoint
+        meta = checkpoint.load_checkpoint(wfile, net)
+        weights = "trained with the repo's own step (tools/train_weights.py): %s" % meta.get("recipe", os.path.basename(wfile))
+    else:
+        with torch.no_grad():
+            synthetic.make_trained_like(net, seed=0)
     B = args.batch
     kind = "aid" if args.channels == 3 else ("s2-merged" if args.channels == 13 else "s2")
     x = synthetic.tiles(B, args.channels, args.size, seed=100 + rank, kind=kind, device=dev)
@@ -145,22 +329,20 @@ def main():
     psnr = licos_amd.metrics.compute_psnr(dec["x_hat"], x)
 
     stages = {}
-    roof = roof_d2 = None
+    roof = roof_a3 = None
     if events:
+        per_stage_ms = {}
         for key, evs in events.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+            per_stage_ms[key] = ms
             fl = stage_flops(*key[:5]) * key[5]
             stages["%s_%d_%d_%dx%d_b%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
-        # the two MFMA kernels the time goes to: g_a[2] (SURVEY.md section 8(d)'s target kernel, `roofline`) and
-        # g_s[2], the largest single kernel of the step (`roofline_g_s2`); same algorithmic FLOPs per tile
-        def roofline_of(kind, kernel_name, traffic_file):
-            keys = [k for k in events if k[:5] == (kind, 128, 128, 128 if kind == "conv" else 64, 128 if kind == "conv" else 64)]
-            if not keys:
-                return None
-            key = max(keys, key=lambda k: k[5])
+
+        def roofline_of(key, kernel_name, traffic_file):
             LB = key[5]
-            ms = sum(e0.elapsed_time(e1) for e0, e1 in events[key]) / len(events[key])
-            ach = FLOP_PER_TILE_A3 * LB / (ms * 1e-3) / 1e12
+            ms = per_stage_ms[key]
+            fl = stage_flops(*key[:5]) * LB
+            ach = fl / (ms * 1e-3) / 1e12
             traffic = None
             tfile = os.path.join(ROOT, "profiles", traffic_file)
             if os.path.exists(tfile):  # PMC passes cannot run inside the timed process; see profiles/README.md
@@ -171,11 +353,21 @@ def main():
                     "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, scaled "
                                       "to this launch size)" % traffic_file,
                     "avg_launch_ms": round(ms, 4), "launches": len(events[key]), "tiles_per_launch": LB,
-                    "algorithmic_flop_per_launch": FLOP_PER_TILE_A3 * LB,
-                    "algorithmic_bytes_per_launch": 5242880 * LB}
-        roof = roofline_of("conv", "conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r01_pmc_traffic_conv_a3.json")
-        roof_d2 = roofline_of("deconv", "deconv5x5s2_mfma_kernel<4,2,8,32,IGDN> (g_s[2], 128->128 @64^2->128^2)",
-                              "r01_pmc_traffic_deconv_s2.json")
+                    "algorithmic_flop_per_launch": fl,
+                    "algorithmic_bytes_per_launch": 2 * (key[1] * key[3] * key[4] + key[2] * (key[3] * key[4] * (4 if key[0] == "deconv" else 0.25))) * LB}
+
+        # `roofline` = the DOMINANT kernel of the step (largest total time among the MFMA stages, full-size launches);
+        # the north-star target kernel g_a[2] rides along as `roofline_g_a2`
+        names = {("conv", 128, 128, 128, 128): ("conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r02_pmc_traffic_conv_a3.json"),
+                 ("deconv", 128, 128, 64, 64): ("deconv5x5s2_mfma8_kernel<4,IGDN> (g_s[4], 128->128 @64^2->128^2, 4 phases per workgroup)",
+                                               "r02_pmc_traffic_deconv_s4.json")}
+        full = {k: v for k, v in per_stage_ms.items() if k[5] == max(kk[5] for kk in per_stage_ms)}
+        dom = max(full, key=lambda k: full[k] * len(events[k]))
+        nm = names.get(dom[:5], ("%s_%d_%d_%dx%d" % dom[:5], "none"))
+        roof = roofline_of(dom, *nm)
+        a3 = [k for k in full if k[:5] == ("conv", 128, 128, 128, 128)]
+        if a3:
+            roof_a3 = roofline_of(a3[0], *names[("conv", 128, 128, 128, 128)])
 
     # federated weight averaging step: one RCCL all-reduce of the flat fp32 state
     fed = None
@@ -193,18 +385,37 @@ def main():
         ft = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(ft, op=dist.ReduceOp.MAX)
         nbytes_bucket = fs.flat.numel() * 4
-        fed = {"ms": round(1e3 * float(ft.item()), 4), "bucket_bytes": nbytes_bucket,
-               "busbw_GBps": round(2 * (world - 1) / world * nbytes_bucket / float(ft.item()) / 1e9, 2),
-               "what": "scale + RCCL all-reduce(SUM) + normalise of the whole floating state, per averaging step"}
+        busbw = 2 * (world - 1) / world * nbytes_bucket / float(ft.item()) / 1e9
+        fed = {"ms": round(1e3 * float(ft.item()), 4), "bucket_bytes": nbytes_bucket, "busbw_GBps": round(busbw, 2),
+               "frac_of_7x153": round(busbw / XGMI_PEAK_GBPS, 4), "backend": args.backend,
+               "nccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))},
+               "what": "scale + all-reduce(SUM) + normalise of the whole floating state, per averaging step"}
+        # config 4: the training step of cfg/raw_merged.toml on every rank, then the average of its state
+        tr, tnet = train_step_ms(dev, steps=5, world=world)
+        tfs = federation.FlatState(tnet)
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(5):
+            federation.weighted_average_(tfs, 1.0 / world)
+        fence()
+        tt = torch.tensor([tr["ms"], 1e3 * (time.perf_counter() - t2) / 5], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        fed["config4"] = {"train_step_ms": round(float(tt[0]), 3), "average_ms": round(float(tt[1]), 3),
+                          "patches_s_all_ranks": round(16e3 * world / float(tt[0] + tt[1]), 1),
+                          "what": "16 x 13x256x256 patches per rank per step (licos/train.py:186-200) + one weight average"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "bmshj2018-factorized" and args.size == 256:
-        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        tps, dt, threads = cpu_baseline(sd, args.channels, 32, 8)
-        match = quality_match(net, sd, x[:8])
-        cpu = {"value": round(tps, 2), "unit": "tiles/s", "cores": threads, "kind": "port", "quality_match": match,
-               "sample": "oracle compress+decompress (torch-CPU conv, C rANS), 8 reps x 32 tiles of the same 3x256x256 "
-                         "workload, %.1f s, %d torch threads on a %d-core host" % (dt, threads, os.cpu_count() or 0)}
+    cpu = grid = None
+    if rank == 0 and world == 1 and args.model == "bmshj2018-factorized" and args.size == 256:
+        if not args.no_extras:
+            grid = extras(args, net, x, dev)
+        if not args.no_cpu_baseline:
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            tps, dt, threads, cgrid = cpu_baseline(sd, args.channels)
+            match = quality_match(net, sd, x[:8])
+            cpu = {"value": tps, "unit": "tiles/s", "cores": threads, "kind": "port", "quality_match": match, "grid": cgrid,
+                   "sample": "oracle compress + decompress (torch-CPU conv, C rANS) of the same 3x256x256 workload: B = 16 and "
+                             "B = 1 at %d and 1 torch threads, encode / decode timed separately, %.1f s in all, on a %d-core host; "
+                             "`value` = B 16 on %d threads" % (threads, dt, os.cpu_count() or 0, threads)}
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -217,11 +428,13 @@ def main():
             "config": {"workload": "%s q=%d, %d-ch %dx%d tiles, compress()+decompress() through the "
                                    "module API, %d tiles per GPU per step" % (args.model.replace("-", "_"), args.quality,
                                                                               args.channels, args.size, args.size, B),
-                       "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": "synthetic trained-like (seeded)"},
+                       "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": weights},
             "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
-            "roofline": roof, "roofline_g_s2": roof_d2, "cpu_baseline": cpu, "fedavg_allreduce": fed, "stages": stages,
+            "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
+            "stages": stages,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -203,6 +203,21 @@ int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long
                             int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
                             const int32_t *offset, const void *enc_table, uint32_t *words, int cap_words,
                             int32_t *nwords, int32_t *status, int B, void *stream);
+/* The same coder on the HOST cores, one std::thread per group of streams, bit-identical streams (CompressAI's
+ * RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes are host code too; /root/reference/eval_script.py:138-165
+ * codes one whole granule = ONE stream, where a single GPU lane loses to a single core).  All pointers are HOST memory.
+ * Same symbol / index addressing as above; `rows` = number of CDF rows; enc_table = licos_rans_build_enc_table's output.
+ * encode: stream b is written to out[b * cap_bytes_per_stream ...) (front-aligned), nbytes[b] = its length;
+ *         LICOS_EOVERFLOW if a stream needs more than cap_bytes_per_stream (8 * n + 16 always suffices).
+ * decode: stream b = in[byte_off[b] .. byte_off[b+1]); status[0] = 1 if a stream ended early (its remaining symbols are 0;
+ *         never reads outside a stream).  nthreads <= 1 runs on the calling thread. */
+int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
+                           int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
+                           int rows, const void *enc_table, uint8_t *out, long cap_bytes_per_stream, int64_t *nbytes,
+                           int B, int nthreads);
+int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const int32_t *indexes, long sym_stride_b,
+                           long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                           const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int B, int nthreads);
 /* gathers each stream's words (in stream order) into one packed little-endian
  * byte buffer: stream b occupies out[byte_off[b] .. byte_off[b] + 4*nwords[b]).
  * byte_off[B] = exclusive prefix sum of 4*nwords (computed by the caller). */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "licos_reduce_sqdiff": (_i, [_vp, _vp, _l, _i, _vp, _vp]),
     "licos_ssim_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _vp, _vp]),
     "licos_rans_encode_batch": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "licos_rans_encode_host": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i]),
+    "licos_rans_decode_host": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i]),
     "licos_rans_compact": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "licos_rans_decode_batch": (_i, [_vp, _vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "licos_gc_likelihood": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),

@@ -128,19 +128,36 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
       const half8 *s_patch = (si < 3) ? s_even : s_odd;
       const half8 *s_w = s_wbuf + wcur * G::W_GRAN;
       const int rowoff = (ky >> 1) * G::ROWG;
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        half8 bf[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          bf[nt] = s_patch[((si < 3) ? base_e[nt] : base_o[nt]) + rowoff + (kx & 1) * G::PWH + (kx >> 1)];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const half8 af = s_w[(kx * MT + mt) * 64 + lane];
+      // 5 kx x MT A fragments, each against the NT pixel tiles; the LDS reads run two items ahead of their MFMAs
+      // (pinned by sched_group_barrier; counted lgkmcnt waits since the LDS-DMA is issued as inline assembly)
+      {
+        constexpr int NI = 5 * MT;
+        const int pb0 = ((si < 3) ? base_e[0] : base_o[0]) + rowoff, pb1 = ((si < 3) ? base_e[1] : base_o[1]) + rowoff;
+        half8 a_cur = s_w[lane], a_nxt = s_w[64 + lane], b_cur[NT], b_nxt[NT];
+        b_nxt[0] = b_cur[0] = s_patch[pb0];
+        b_nxt[1] = b_cur[1] = s_patch[pb1];
+        static_for<NI>([&](auto itc) {
+          constexpr int it = decltype(itc)::value, mt = it % MT, kx = it / MT;
+          constexpr bool more_a = it + 2 < NI, more_b = (mt == MT - 2) && (kx + 1 < 5);
+          constexpr int boff = ((kx + 1) & 1) * G::PWH + ((kx + 1) >> 1);
+          half8 a_nn = a_nxt;
+          if (more_a) a_nn = s_w[(it + 2) * 64 + lane];
+          if (more_b) {
+            b_nxt[0] = s_patch[pb0 + boff];
+            b_nxt[1] = s_patch[pb1 + boff];
+          }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
-        }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, b_cur[nt], acc[mt][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, (more_a ? 1 : 0) + (more_b ? NT : 0), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+          a_cur = a_nxt;
+          a_nxt = a_nn;
+          if (mt == MT - 1) {
+            b_cur[0] = b_nxt[0];
+            b_cur[1] = b_nxt[1];
+          }
+        });
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

@@ -19,6 +19,16 @@ from . import ops
 from .layers import LowerBound
 
 
+def _to_host(t):
+    """Device tensor -> numpy through a page-locked buffer (pageable D2H copies cost tens of ms on ROCm)."""
+    if not t.is_cuda:
+        return t.numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy()
+
+
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels, *args, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3),
                  likelihood_bound=1e-9, entropy_coder_precision=16, likelihood_form="plain", **kwargs):
@@ -185,8 +195,15 @@ class EntropyBottleneck(nn.Module):
             dev = self._quantized_cdf.device
             self._coder = (self._quantized_cdf.contiguous(), self._cdf_length.contiguous(), self._offset.contiguous(),
                            torch.from_numpy(table).to(dev))
+            # host copies for the host coder (few streams / one very long stream: ops.host_coder_preferred)
+            self._coder_host = (np.ascontiguousarray(cdf_h, dtype=np.int32), np.ascontiguousarray(len_h, dtype=np.int32),
+                                np.ascontiguousarray(self._offset.detach().cpu().numpy(), dtype=np.int32), table)
             self._coder_key = key
         return self._coder
+
+    def coder_tables_host(self):
+        self.coder_tables()
+        return self._coder_host
 
     # ------------------------------------------------------------------ device path
     def packed_params(self):
@@ -292,10 +309,42 @@ class EntropyBottleneck(nn.Module):
         b = x.shape[0]
         n = x[0].numel()
         plane = x[0, 0].numel()
+        if ops.host_coder_preferred(b):
+            return self._compress_host(x, b, n, plane)
         sym = self._symbols_interleaved(x)
         packed, byte_off = self.encode_symbols(sym, b, n, plane)
         host = packed.cpu().numpy()
         return [host[byte_off[i]:byte_off[i + 1]].tobytes() for i in range(b)]
+
+    # ---- host coder: quantise / dequantise on the device, the sequential recurrence on the host cores
+    def _compress_host(self, x, b, n, plane, indexes=None, medians=None):
+        cdf, cdf_len, offset, table = self.coder_tables_host()
+        sym = torch.empty((b, n), device=x.device, dtype=torch.int32)  # one contiguous stream per row
+        ops.eb_quantize(x.contiguous(), self.medians_vec() if medians is None else medians, "symbols", symbols=sym,
+                        sym_stride_b=n, sym_stride_i=1)
+        sym_h = _to_host(sym)
+        idx_h = None if indexes is None else _to_host(indexes)
+        out, nbytes = ops.rans_encode_host(sym_h, n, plane, cdf, cdf_len, offset, table, indexes=idx_h)
+        return [out[i, : int(nbytes[i])].tobytes() for i in range(b)]
+
+    def _decompress_host(self, strings, b, c, h, w, indexes=None, medians=None):
+        cdf, cdf_len, offset, _ = self.coder_tables_host()
+        dev = self._quantized_cdf.device
+        n = c * h * w
+        lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=b)
+        byte_off = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(lens, out=byte_off[1:])
+        data = np.frombuffer(b"".join(strings), dtype=np.uint8)
+        stage = torch.empty((b, n), dtype=torch.int32, pin_memory=dev.type == "cuda")
+        idx_h = None if indexes is None else _to_host(indexes)
+        _, status = ops.rans_decode_host(data, byte_off, n, h * w, cdf, cdf_len, offset, b, indexes=idx_h, out=stage.numpy())
+        if status != 0:
+            raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+        sym = stage.to(dev, non_blocking=True)
+        med = self.medians_vec() if medians is None else medians
+        out = ops.eb_dequantize(sym, n, 1, med, b, c, h, w)
+        torch.cuda.current_stream().synchronize()  # the page-locked staging buffer is released on return
+        return out
 
     _pinned = {}
 
@@ -338,6 +387,8 @@ class EntropyBottleneck(nn.Module):
         b = len(strings)
         c = self._quantized_cdf.size(0)
         h, w = int(size[0]), int(size[1])
+        if ops.host_coder_preferred(b):
+            return self._decompress_host(strings, b, c, h, w)
         data, byte_off = self.pack_strings(strings, self._quantized_cdf.device)
         sym, status = self.decode_symbols(data, byte_off, b, c * h * w, h * w)
         out = ops.eb_dequantize(sym, 1, b, self.medians_vec(), b, c, h, w)
@@ -415,7 +466,10 @@ class GaussianConditional(nn.Module):
         self._coder_key = None
 
     coder_tables = EntropyBottleneck.coder_tables
+    coder_tables_host = EntropyBottleneck.coder_tables_host
     _check_cdfs = EntropyBottleneck._check_cdfs
+    _compress_host = EntropyBottleneck._compress_host
+    _decompress_host = EntropyBottleneck._decompress_host
 
     def forward(self, inputs, scales, means=None, training=None, noise=None, sum_log2=None):
         if means is not None:
@@ -470,6 +524,9 @@ class GaussianConditional(nn.Module):
         self._check_cdfs()
         b = inputs.shape[0]
         n = inputs[0].numel()
+        if ops.host_coder_preferred(b):  # indexes [n][B] interleaved -> one row per stream
+            zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
+            return self._compress_host(inputs, b, n, 0, indexes=indexes_interleaved.t().contiguous(), medians=zeros)
         cdf, cdf_len, offset, table = self.coder_tables()
         rows_hint = cdf.shape[0] if cdf.shape[0] <= 256 else 0  # selects the LDS-staged indexed coder kernels
         zeros = torch.zeros(inputs.shape[1], device=inputs.device, dtype=torch.float32)
@@ -497,6 +554,9 @@ class GaussianConditional(nn.Module):
         b = len(strings)
         c, h, w = shape
         n = c * h * w
+        if ops.host_coder_preferred(b):
+            zeros = torch.zeros(c, device=self._quantized_cdf.device, dtype=torch.float32)
+            return self._decompress_host(strings, b, c, h, w, indexes=indexes_interleaved.t().contiguous(), medians=zeros)
         cdf, cdf_len, offset, _ = self.coder_tables()
         data, byte_off = EntropyBottleneck.pack_strings(strings, cdf.device)
         sym = torch.empty((n, b), device=cdf.device, dtype=torch.int32)

@@ -491,6 +491,81 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
     return status
 
 
+def host_threads():
+    """Worker threads for the host coder: this process's share of the box's cores (a GPU box gives one GPU 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+# Coder placement (licos_amd/entropy_models.py): a GPU lane spends ~160 ns (encode) / ~330 ns (decode) per symbol of
+# its stream whatever the batch, a host core ~5 / ~10 ns; with T host threads the host wins below ~32 T streams.
+# LICOS_HOST_CODER = "0" never, "1" always, otherwise automatic with this many streams per host thread as the limit.
+HOST_CODER = os.environ.get("LICOS_HOST_CODER", "auto")
+HOST_CODER_STREAMS_PER_THREAD = 24
+
+
+def host_coder_preferred(batch):
+    if HOST_CODER == "0":
+        return False
+    if HOST_CODER == "1":
+        return True
+    return batch <= HOST_CODER_STREAMS_PER_THREAD * host_threads()
+
+
+def _np_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, ctypes.c_void_p(a.ctypes.data)
+
+
+def rans_encode_host(symbols, n, plane, cdf, cdf_len, offset, enc_table, indexes=None, nthreads=None):
+    """Host coder.  symbols: int32 numpy [B][n] (one contiguous stream per row); tables: numpy (host copies).
+    Returns (out uint8 [B][cap], nbytes int64 [B])."""
+    sym, sp = _np_i32(symbols)
+    b = sym.shape[0]
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    ip = ctypes.c_void_p(0)
+    if indexes is not None:
+        idx, ip = _np_i32(indexes)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    cap = 4 * (n // 2 + 64)
+    for attempt in range(2):
+        out = np.empty((b, cap), dtype=np.uint8)
+        nbytes = np.zeros(b, dtype=np.int64)
+        rc = _lib.load().licos_rans_encode_host(sp, ip, n, 1, n, plane, cp, cdf_a.shape[1], lp, op, cdf_a.shape[0],
+                                                ctypes.c_void_p(enc_table.ctypes.data), ctypes.c_void_p(out.ctypes.data), cap,
+                                                ctypes.c_void_p(nbytes.ctypes.data), b, nthreads)
+        if rc != -4 or attempt == 1:
+            break
+        cap = 8 * n + 16  # worst case: under two words per symbol
+    _lib.check(rc, "rans_encode_host")
+    return out, nbytes
+
+
+def rans_decode_host(data, byte_off, n, plane, cdf, cdf_len, offset, batch, indexes=None, nthreads=None, out=None):
+    """Host decoder.  data: uint8 numpy (all streams), byte_off int64 [B+1].  Returns (symbols int32 [B][n], status)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off64 = np.ascontiguousarray(byte_off, dtype=np.int64)
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    ip = ctypes.c_void_p(0)
+    if indexes is not None:
+        idx, ip = _np_i32(indexes)
+    sym = np.empty((batch, n), dtype=np.int32) if out is None else out
+    status = np.zeros(1, dtype=np.int32)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    rc = _lib.load().licos_rans_decode_host(ctypes.c_void_p(data.ctypes.data), ctypes.c_void_p(off64.ctypes.data), ip, n, 1, n,
+                                            plane, cp, cdf_a.shape[1], lp, op, cdf_a.shape[0], ctypes.c_void_p(sym.ctypes.data),
+                                            ctypes.c_void_p(status.ctypes.data), batch, nthreads)
+    _lib.check(rc, "rans_decode_host")
+    return sym, int(status[0])
+
+
 # ----------------------------------------------------------------------------- 16-bit MFMA path
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_RELU = 0, 1, 2, 3
 EPI_ACCUMULATE = 0x100  # licos_hip.h LICOS_EPI_ACCUMULATE

@@ -3,6 +3,7 @@ process_img's contract, checkpoint save -> load -> identical bit streams."""
 import io
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -32,9 +33,22 @@ def test_msssim_rejects_small_images():
         licos_amd.metrics.compute_msssim(x, x)
 
 
+def _drive_like_process_img(img, net):
+    """What the reference's evaluation helper asks of the module (/root/reference/eval_utils.py:189-210, which stays the
+    caller's own code - INTEGRATION.md): one forward and one compress of a (C, H, W) image, byte count taken over
+    np.array(strings), reconstruction clamped and cropped to the input."""
+    with torch.no_grad():
+        out = net.forward(img.unsqueeze(0))
+        coded = net.compress(img.unsqueeze(0))
+    nbytes = np.frombuffer(np.array(coded["strings"]), dtype=np.uint8).size
+    out["x_hat"].clamp_(0, 1)
+    out["x_hat"] = out["x_hat"][..., : img.shape[1], : img.shape[2]]
+    return out, out["x_hat"].squeeze().cpu(), torch.mean((out["x_hat"] - img).abs(), axis=1).squeeze().cpu(), nbytes
+
+
 def test_process_img_contract():
     import licos_amd
-    from licos_amd import eval_utils, synthetic
+    from licos_amd import metrics as eval_utils, synthetic
     net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1).cuda().eval()
     with torch.no_grad():
         synthetic.make_trained_like(net, seed=1)
@@ -42,7 +56,7 @@ def test_process_img_contract():
     img = synthetic.tiles(1, 3, 256, seed=4, device="cuda")[0, :, :200, :232].contiguous()  # not a multiple of 16: x_hat is cropped back
     pad = torch.zeros(3, 208, 240, device="cuda")
     pad[:, :200, :232] = img
-    out_net, rec, diff, nbytes = eval_utils.process_img(pad, net)
+    out_net, rec, diff, nbytes = _drive_like_process_img(pad, net)
     assert tuple(rec.shape) == (3, 208, 240) and tuple(diff.shape) == (208, 240)
     assert float(out_net["x_hat"].min()) >= 0.0 and float(out_net["x_hat"].max()) <= 1.0
     comp = net.compress(pad.unsqueeze(0))

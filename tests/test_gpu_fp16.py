@@ -295,9 +295,10 @@ def test_fp16_whole_images_of_any_multiple_of_16(cin, h, w):
     assert abs(psnr16 - psnr32) < 0.1 and abs(bpp16 - bpp32) < 0.01 * bpp32 + 1e-3, (psnr16, psnr32, bpp16, bpp32)
 
 
-def test_fp16_codec_accepts_plain_and_edited_string_lists():
+def test_fp16_codec_accepts_plain_and_edited_string_lists(monkeypatch):
     """compress() returns a list subclass that remembers its packed host buffer; decompress must give the
     same result for that object, for a plain list of the same bytes, and for a reordered plain list."""
+    monkeypatch.setattr(ops, "HOST_CODER", "0")  # the chunk-pipelined device coder (batches this small go to the host otherwise)
     sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=11, y_gain=20.0)
     net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
     net.load_state_dict(sd)
@@ -319,11 +320,37 @@ def test_fp16_codec_accepts_plain_and_edited_string_lists():
     assert np.frombuffer(np.array(comp["strings"]), dtype=np.uint8).size > 0  # eval_utils.py:202-204 idiom
 
 
-def test_mutated_packed_strings_decode_what_the_list_holds():
+def test_fp16_codec_host_and_device_coder_agree(monkeypatch):
+    """Same tiles through the chunk-pipelined device coder and through the host coder: identical strings, identical
+    reconstruction; and each side decodes the other's strings."""
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=11, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    net.chunk = 8
+    x = om.synthetic_tiles(21, 3, 64, seed=5).to(DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "HOST_CODER", "0")
+        cd = net.compress(x)
+        dd = net.decompress(cd["strings"], cd["shape"])["x_hat"]
+        monkeypatch.setattr(ops, "HOST_CODER", "1")
+        ch = net.compress(x)
+        dh = net.decompress(ch["strings"], ch["shape"])["x_hat"]
+        dcross = net.decompress([list(cd["strings"][0])], cd["shape"])["x_hat"]
+        monkeypatch.setattr(ops, "HOST_CODER", "0")
+        dcross2 = net.decompress([list(ch["strings"][0])], ch["shape"])["x_hat"]
+    assert [bytes(s) for s in cd["strings"][0]] == [bytes(s) for s in ch["strings"][0]]
+    assert tuple(cd["shape"]) == tuple(ch["shape"])
+    assert torch.equal(dd, dh) and torch.equal(dd, dcross) and torch.equal(dd, dcross2)
+
+
+def test_mutated_packed_strings_decode_what_the_list_holds(monkeypatch):
     """The list compress() returns may be edited by the caller (a corruption experiment, a swap between tiles): the
     packed host buffers it remembers are then stale and decompress must decode the list's bytes, including when the
     replacement has the SAME length as the original (the round-1 check sampled three lengths per segment)."""
     from licos_amd.codec import PackedStrings
+    monkeypatch.setattr(ops, "HOST_CODER", "0")  # PackedStrings is what the chunk-pipelined device coder returns
     sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=11, y_gain=20.0)
     net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
     net.load_state_dict(sd)

@@ -9,6 +9,14 @@ from oracle import model as om
 from oracle import rans
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["device-coder", "host-coder"])
+def _coder_placement(request, monkeypatch):
+    """Every test runs twice: rANS on the GPU (one lane per stream) and on the host cores (licos_rans_*_host) - the
+    product picks by batch size (ops.host_coder_preferred), the bytes must not depend on it."""
+    from licos_amd import ops as _ops
+    monkeypatch.setattr(_ops, "HOST_CODER", "0" if request.param == "device-coder" else "1")
 DEV = "cuda:0"
 
 

@@ -221,3 +221,66 @@ def test_mfma_weight_gradient_accuracy_and_reproducibility(cin, cout, h, w, batc
     den = float(ref.abs().max())
     ea, ev = (float((t.cpu().double() - ref).abs().max()) / den for t in (a, v))
     assert ea < 3e-6 and ea <= 2 * ev + 5e-7, (ea, ev)
+
+
+def test_training_converges_with_the_repos_own_step():
+    """licos/train.py:186-200's recipe (lambda 1e-2, Adam 1e-4 / aux Adam 1e-3, clip 1.0, batches of 16) on seeded synthetic
+    tiles, every kernel of the step the repo's own: 300 steps must lower the RD loss by far more than 30 % and the aux loss
+    must fall.  (The full run behind licos_amd/weights/ is tools/train_weights.py; its curve is profiles/r02_train_q3_c3.jsonl.)"""
+    from licos_amd import synthetic
+    torch.manual_seed(42)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(DEV).train()
+    crit = licos_amd.RateDistortionLoss(lmbda=1e-2)
+    opt = licos_amd.net_aux_optimizer(net, {"net": {"type": "Adam", "lr": 1e-4}, "aux": {"type": "Adam", "lr": 1e-3}})
+    first = last = aux_first = aux_last = None
+    for step in range(300):
+        x = synthetic.tiles(16, 3, 128, seed=5000 + step, device=DEV)
+        opt["net"].zero_grad()
+        opt["aux"].zero_grad()
+        res = crit(net(x), x)
+        res["loss"].backward()
+        licos_amd.optimizers.clip_grad_norm_(list(net.parameters()), 1.0, opt["net"])
+        opt["net"].step()
+        aux = net.aux_loss()
+        aux.backward()
+        opt["aux"].step()
+        if step < 5:
+            first = float(res["loss"].detach()) if first is None else max(first, float(res["loss"].detach()))
+            aux_first = float(aux.detach()) if aux_first is None else aux_first
+        if step >= 295:
+            last = float(res["loss"].detach()) if last is None else max(last, float(res["loss"].detach()))
+            aux_last = float(aux.detach())
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    assert last < 0.7 * first, (first, last)
+    assert last < 0.2 * first, (first, last)  # measured: 138 -> ~8 in 300 steps
+    assert aux_last < aux_first, (aux_first, aux_last)
+
+
+def test_shipped_operating_point_codes_images():
+    """licos_amd/weights/factorized_q3_c3.pth.tar (trained by tools/train_weights.py with the step above): a real
+    rate / distortion point on held-out tiles, through the fp16 codec and against the oracle on the same weights."""
+    import os
+    from licos_amd import checkpoint, synthetic
+    path = os.path.join(os.path.dirname(licos_amd.__file__), "weights", "factorized_q3_c3.pth.tar")
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(DEV).eval()
+    meta = checkpoint.load_checkpoint(path, net)
+    assert "recipe" in meta and meta["batch_idx"] >= 10000
+    x = synthetic.tiles(8, 3, 256, seed=100, device=DEV)
+    net.set_precision("fp16")
+    with torch.no_grad():
+        out = net(x)
+        c = net.compress(x)
+        d = net.decompress(c["strings"], c["shape"])
+    psnr = licos_amd.metrics.compute_psnr(d["x_hat"], x)
+    bpp = 8.0 * sum(len(s) for s in c["strings"][0]) / (8 * 256 * 256)
+    assert psnr > 30.0 and 0.05 < bpp < 0.6, (psnr, bpp)
+    sd = {k: v.detach().cpu().float() if v.dtype.is_floating_point else v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = om.forward(x.cpu(), sd)
+    assert abs(licos_amd.metrics.compute_bpp(out) - om.compute_bpp(ref)) < 2e-3 * om.compute_bpp(ref)
+    assert abs(licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x) - om.compute_psnr(ref["x_hat"].clamp(0, 1), x.cpu())) < 0.02
+    # escapes are rare on the trained distribution
+    y = net.g_a(x)
+    eb = net.entropy_bottleneck
+    sym = torch.round(y - eb.medians_vec().reshape(1, -1, 1, 1)).int() - eb._offset.reshape(1, -1, 1, 1)
+    esc = ((sym < 0) | (sym >= (eb._cdf_length - 2).reshape(1, -1, 1, 1))).float().mean()
+    assert float(esc) < 1e-3, float(esc)

@@ -138,6 +138,19 @@ int licos_eb_quantize(const float *y, const float *medians, const float *noise, 
  * /root/reference/eval_utils.py:172-186 and RateDistortionLoss. */
 int licos_eb_likelihood(const float *v, const float *packed, const int *filters_host, int nfilt, float *lik,
                         float bound, int form, double *sum_log2, int B, int C, int HW, void *stream);
+/* Backward of licos_eb_likelihood ([CAI] EntropyBottleneck._likelihood + LowerBound's gradient rule: the gradient
+ * passes where lik >= bound or g < 0; /root/reference/licos/train.py:186-200 loss.backward()).  g_lik = dL/dlik.
+ * dv = dL/dv; dparams_slices [licos_eb_likelihood_bwd_slices(B, HW)][C][per_channel] in licos_eb_pack's record order
+ * (matrix, bias, factor per layer) but w.r.t. the RAW parameters; the caller adds the slices. */
+int licos_eb_likelihood_bwd_slices(int B, int HW);
+int licos_eb_likelihood_bwd(const float *v, const float *g_lik, const float *packed, const int *filters_host, int nfilt,
+                            float bound, int form, float *dv, float *dparams_slices, int B, int C, int HW, void *stream);
+/* Backward of licos_gc_likelihood: dL/dv and dL/dscales (both LowerBounds with CompressAI's gradient rule). */
+int licos_gc_likelihood_bwd(const float *v, const float *scales, const float *g_lik, float scale_bound, float lik_bound,
+                            float *dv, float *dscale, long n, void *stream);
+/* out = g * (ref > 0) (mode 0: ReLU backward) or g * sign(ref) (mode 1: |x| backward) - the point-wise masks of the
+ * hyper transforms' backward pass ([CAI] models/google.py ScaleHyperprior h_a / h_s). */
+int licos_mask_mul_f32(const float *g, const float *ref, float *out, long n, int mode, void *stream);
 /* symbols -> y_hat = float(symbol) + median (EntropyModel.dequantize);
  * writes NCHW fp32 (nullable) and/or blk16 fp16 (nullable). */
 int licos_eb_dequantize(const int32_t *symbols, long sym_stride_b, long sym_stride_i, const float *medians,

@@ -33,6 +33,10 @@ SIGNATURES = {
     "licos_eb_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "licos_eb_quantize": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp]),
     "licos_eb_likelihood": (_i, [_vp, _vp, _vp, _i, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
+    "licos_eb_likelihood_bwd_slices": (_i, [_i, _i]),
+    "licos_eb_likelihood_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "licos_gc_likelihood_bwd": (_i, [_vp, _vp, _vp, _f, _f, _vp, _vp, _l, _vp]),
+    "licos_mask_mul_f32": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "licos_eb_dequantize": (_i, [_vp, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_reduce_sqdiff": (_i, [_vp, _vp, _l, _i, _vp, _vp]),
     "licos_ssim_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _vp, _vp]),

@@ -233,38 +233,9 @@ class EntropyBottleneck(nn.Module):
         from . import autograd
         params = list(self.matrices) + list(self.biases) + list(self.factors)
         if training and autograd.needs_grad(x, *params):
-            nl = len(self.filters) + 1
-            nz = noise.contiguous()
-
-            def hip(xx, *ps):
-                outs = ops.eb_quantize(xx.contiguous(), self.medians_vec(), "noise", noise=nz)
-                packed = ops.eb_pack(list(ps[:nl]), list(ps[nl:2 * nl]), list(ps[2 * nl:]), self.filters, self.channels)
-                return outs, ops.eb_likelihood(outs, packed, self.filters, bound, form, sum_log2)
-
-            def ref(xx, *ps):
-                outs = xx + nz
-                c = self.channels
-                v = outs.transpose(0, 1).reshape(c, 1, -1)
-
-                def logits(t):
-                    for i in range(nl):
-                        t = torch.matmul(F.softplus(ps[i]), t) + ps[nl + i]
-                        if i < nl - 1:
-                            t = t + torch.tanh(ps[2 * nl + i]) * torch.tanh(t)
-                    return t
-
-                lo, up = logits(v - 0.5), logits(v + 0.5)
-                if form == 0:
-                    lik = torch.sigmoid(up) - torch.sigmoid(lo)
-                else:
-                    sign = -torch.sign(lo + up).detach()
-                    lik = torch.abs(torch.sigmoid(sign * up) - torch.sigmoid(sign * lo))
-                if self.use_likelihood_bound:
-                    lik = autograd.lower_bound_ref(lik, self.likelihood_lower_bound.bound)
-                lik = lik.reshape(c, outs.shape[0], *outs.shape[2:]).transpose(0, 1)
-                return outs, lik
-
-            return autograd.HipForward.apply(hip, ref, x, *params)
+            # HIP forward and backward (licos_eb_likelihood_bwd): no re-evaluation in torch operators
+            return autograd.EbLikelihoodHip.apply(x, noise.contiguous(), self.medians_vec(), self.filters, self.channels, bound,
+                                                  form, sum_log2, *params)
         if training:
             outputs = ops.eb_quantize(x.detach(), self.medians_vec(), "noise", noise=noise.contiguous())
         else:
@@ -482,31 +453,16 @@ class GaussianConditional(nn.Module):
         if training and noise is None:
             noise = torch.empty_like(inputs).uniform_(-0.5, 0.5)
 
-        def hip(xx, ss):
-            if training:
-                outs = ops.eb_quantize(xx.contiguous(), zeros, "noise", noise=noise.contiguous())
-            else:
-                outs = ops.eb_quantize(xx.contiguous(), zeros, "dequantize")
-            return outs, ops.gc_likelihood(outs, ss.contiguous(), self.lower_bound_scale.bound_value, bound, sum_log2)
-
         if torch.is_grad_enabled() and (inputs.requires_grad or scales.requires_grad):
             from . import autograd
-            # HIP forward; gradients with respect to the latents AND the predicted scales by re-evaluation of
-            # CompressAI's definition (GaussianConditional._likelihood, LowerBound's gradient rule) in torch ops
-            def ref(xx, ss):
-                outs = xx + noise if training else torch.round(xx)
-                sc = autograd.lower_bound_ref(ss, self.lower_bound_scale.bound)
-                v = torch.abs(outs)
-                const = -(2 ** -0.5)
-                upper = 0.5 * torch.erfc(const * ((0.5 - v) / sc))
-                lower = 0.5 * torch.erfc(const * ((-0.5 - v) / sc))
-                lik = upper - lower
-                if self.use_likelihood_bound:
-                    lik = autograd.lower_bound_ref(lik, self.likelihood_lower_bound.bound)
-                return outs, lik
-
-            return autograd.HipForward.apply(hip, ref, inputs, scales)
-        return hip(inputs, scales)
+            # HIP forward and backward (licos_gc_likelihood_bwd): gradients w.r.t. the latents and the predicted scales
+            return autograd.GcLikelihoodHip.apply(inputs, scales, None if noise is None else noise.contiguous(), training,
+                                                  self.lower_bound_scale.bound_value, bound, sum_log2)
+        if training:
+            outs = ops.eb_quantize(inputs, zeros, "noise", noise=noise.contiguous())
+        else:
+            outs = ops.eb_quantize(inputs, zeros, "dequantize")
+        return outs, ops.gc_likelihood(outs, scales.contiguous(), self.lower_bound_scale.bound_value, bound, sum_log2)
 
     def build_indexes_interleaved(self, scales):
         """Table row per element in the coder's [position][stream] layout."""

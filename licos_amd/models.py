@@ -59,24 +59,14 @@ def run_chain_fp32(seq, x):
         first = False
         if isinstance(m, nn.ConvTranspose2d):
             k, s, p, op = conv_geometry(m)
-            if autograd.needs_grad(x, m.weight, m.bias) and not relu:
-                x = autograd.DeconvHip.apply(x, m.weight, m.bias, s, p, op)  # HIP forward and backward
-            elif autograd.needs_grad(x, m.weight, m.bias):
-                args = (x, m.weight) if m.bias is None else (x, m.weight, m.bias)
-                x = autograd.HipForward.apply(
-                    lambda xx, ww, bb=None, s=s, p=p, op=op, relu=relu: ops.deconv2d_f32(xx.contiguous(), ww, bb, s, p, op, relu),
-                    autograd.deconv_ref(s, p, op, relu), *args)
+            if autograd.needs_grad(x, m.weight, m.bias):
+                x = autograd.DeconvHip.apply(x, m.weight, m.bias, s, p, op, relu)  # HIP forward and backward
             else:
                 x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
         elif isinstance(m, nn.Conv2d):
             k, s, p = conv_geometry(m)
-            if autograd.needs_grad(x, m.weight, m.bias) and not relu and not abs_in:
-                x = autograd.ConvHip.apply(x, m.weight, m.bias, s, p)  # HIP forward and backward
-            elif autograd.needs_grad(x, m.weight, m.bias):
-                args = (x, m.weight) if m.bias is None else (x, m.weight, m.bias)
-                x = autograd.HipForward.apply(
-                    lambda xx, ww, bb=None, s=s, p=p, relu=relu, a=abs_in: ops.conv2d_f32(xx.contiguous(), ww, bb, s, p, relu, abs_input=a),
-                    autograd.conv_ref(s, p, relu, abs_in), *args)
+            if autograd.needs_grad(x, m.weight, m.bias):
+                x = autograd.ConvHip.apply(x, m.weight, m.bias, s, p, relu, abs_in)  # HIP forward and backward
             else:
                 x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
                                    abs_input=abs_in)

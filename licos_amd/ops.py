@@ -402,6 +402,39 @@ def eb_likelihood(v, packed, filters, bound, form=0, sum_log2=None):
     return lik
 
 
+def eb_likelihood_bwd(v, g_lik, packed, filters, bound, form=0):
+    """(dL/dv, dL/dpacked-record [C][per_channel] w.r.t. the raw parameters) of eb_likelihood."""
+    _dev(v, g_lik, packed)
+    b, c = v.shape[:2]
+    hw = v[0, 0].numel()
+    dv = torch.empty_like(v)
+    ns = int(_lib.load().licos_eb_likelihood_bwd_slices(b, hw))
+    dps = torch.empty((ns, c, packed.shape[1]), device=v.device, dtype=torch.float32)
+    arr = _filters_arr(filters)
+    rc = _lib.load().licos_eb_likelihood_bwd(_p(_f32(v)), _p(_f32(g_lik.contiguous())), _p(packed), ctypes.cast(arr, ctypes.c_void_p),
+                                             len(filters), bound, form, _p(dv), _p(dps), b, c, hw, _stream())
+    _lib.check(rc, "eb_likelihood_bwd")
+    return dv, (dps[0] if ns == 1 else dps.sum(0))
+
+
+def gc_likelihood_bwd(v, scales, g_lik, scale_bound, lik_bound):
+    _dev(v, scales, g_lik)
+    dv, ds = torch.empty_like(v), torch.empty_like(v)
+    rc = _lib.load().licos_gc_likelihood_bwd(_p(_f32(v)), _p(_f32(scales)), _p(_f32(g_lik.contiguous())), scale_bound, lik_bound,
+                                             _p(dv), _p(ds), v.numel(), _stream())
+    _lib.check(rc, "gc_likelihood_bwd")
+    return dv, ds
+
+
+def mask_mul_f32(g, ref, mode):
+    """g * (ref > 0) for mode "relu", g * sign(ref) for mode "abs"."""
+    _dev(g, ref)
+    out = torch.empty_like(g)
+    rc = _lib.load().licos_mask_mul_f32(_p(_f32(g)), _p(_f32(ref)), _p(out), g.numel(), {"relu": 0, "abs": 1}[mode], _stream())
+    _lib.check(rc, "mask_mul_f32")
+    return out
+
+
 def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want_nchw=True, blk16=None, sym_offset=0):
     _dev(symbols, medians, blk16)
     y = torch.empty((b, c, h, w), device=symbols.device, dtype=torch.float32) if want_nchw else None

@@ -20,6 +20,12 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elementwise_close(a, b, rtol, atol_of_max):
+    """|a - b| <= rtol |b| + atol_of_max * max|b| for EVERY element (the max-norm rel_err above hides small entries)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return bool(((a - b).abs() <= rtol * b.abs() + atol_of_max * float(b.abs().max())).all())
+
+
 def h16(t):
     return t.half().float()
 
@@ -39,7 +45,10 @@ def test_blk16_layout_roundtrip(c, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(3, 128, 64, 64), (128, 128, 64, 64), (128, 128, 32, 32), (128, 192, 32, 32),
-                                           (13, 128, 40, 72), (128, 128, 22, 38), (1, 128, 16, 16), (128, 192, 64, 80)])
+                                           (13, 128, 40, 72), (128, 128, 22, 38), (1, 128, 16, 16), (128, 192, 64, 80),
+                                           # the 8-wave kernel (output >= 16 x 32, rows % 16 == 0): the bench geometry
+                                           # 128^2 -> 64^2, ragged-x maps (Wo % 32 != 0), the 576 x 648 -> 288 x 324 granule map
+                                           (128, 128, 128, 128), (128, 128, 128, 80), (128, 128, 64, 144), (128, 128, 576, 648)])
 def test_conv_stage_exact_operands(cin, cout, h, w):
     g = torch.Generator().manual_seed(cin + cout + h)
     x = h16(torch.randn(2, cin, h, w, generator=g))
@@ -52,8 +61,10 @@ def test_conv_stage_exact_operands(cin, cout, h, w):
     out = ops.conv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 2e-5
+    assert elementwise_close(out, ref, 1e-5, 2e-5)
     outb = ops.conv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=False)
     assert rel_err(ops.blk16_to_nchw_f32(outb, cout), ref) < 1e-3  # fp16 output rounding
+    assert elementwise_close(ops.blk16_to_nchw_f32(outb, cout), ref, 4.9e-4, 2e-5)  # one fp16 rounding of the fp32 sum
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
@@ -229,11 +240,12 @@ def test_model_fp16_matches_oracle_rates(cin, kind):
     nbytes = sum(len(s) for s in om.compress(x, sd)["strings"][0])
     print(f"cin={cin}: y rel err {y_err:.2e}, symbol mismatch {mism:.4f}, bpp {bpp16:.4f} vs {bpp:.4f}, "
           f"PSNR {psnr16:.3f} vs {psnr:.3f} dB, bytes {nbytes16} vs {nbytes}")
-    assert y_err < 1e-2
-    assert mism < 0.05
-    assert abs(bpp16 - bpp) < 0.01 * bpp
-    assert abs(psnr16 - psnr) < 0.1
-    assert abs(nbytes16 - nbytes) < 0.01 * nbytes + 16
+    # ~3x what is measured (y 8.5e-4, mismatch 0.05-0.08 %, bpp < 1e-4 relative, PSNR < 0.001 dB, length within 4 bytes)
+    assert y_err < 3e-3
+    assert mism < 3e-3
+    assert abs(bpp16 - bpp) < 1e-3 * bpp
+    assert abs(psnr16 - psnr) < 0.01
+    assert abs(nbytes16 - nbytes) < 1e-3 * nbytes + 16
     # self-consistency: the decoder reproduces forward()'s reconstruction from the bytes alone
     assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
 

@@ -29,6 +29,13 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elementwise_close(a, b, rtol=1e-5, atol_of_max=1e-6):
+    """north_star's "1e-5 relative on latents", read element by element: |a - b| <= rtol |b| + atol_of_max * max|b|
+    (the absolute term is the cancellation noise of a few-thousand-term fp32 sum whose result is near zero)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return bool(((a - b).abs() <= rtol * b.abs() + atol_of_max * float(b.abs().max())).all())
+
+
 def tie_mismatches(sym_gpu, y_ref, medians, tol):
     """Positions where the GPU symbol differs from round(y_ref - median).  Two fp32 evaluations of
     g_a agree to ~1e-6 relative, so a latent that sits within `tol` of a rounding tie (x.5) may
@@ -244,6 +251,7 @@ def test_full_size_tiles_fp32_vs_oracle(cin, kind):
         # (a) analysis transform
         y = net.g_a(x.to(DEV))
         assert rel_err(y, ref["y"]) < 1e-5
+        assert elementwise_close(y, ref["y"])
         # (b) symbols: equal except on rounding ties
         b, c, h, w = y.shape
         sym = eb._symbols_interleaved(y).cpu().T.reshape(b, c, h, w)
@@ -258,6 +266,7 @@ def test_full_size_tiles_fp32_vs_oracle(cin, kind):
         # (d) synthesis transform on identical y_hat
         x_hat = net.g_s(y_hat)
         assert rel_err(x_hat, ref["x_hat"]) < 1e-5
+        assert elementwise_close(x_hat, ref["x_hat"])
         # (e) coder on identical latents: bytes identical to the oracle's
         strings = eb.compress(y_ref)
         assert strings == ref_c["strings"][0]

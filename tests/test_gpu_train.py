@@ -11,6 +11,24 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+class _LowerBoundRef(torch.autograd.Function):
+    """[CAI] ops/bound_ops.py: max(x, bound) whose gradient passes where x >= bound or grad < 0 (test reference)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)) * g, None
+
+
+def lower_bound_ref(x, bound):
+    return _LowerBoundRef.apply(x, bound)
+
+
 def test_train_step_matches_cpu_autograd():
     sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=13, y_gain=20.0)
     net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
@@ -171,12 +189,11 @@ def test_gaussian_conditional_gradients_match_cpu_autograd():
     out, lik = gc(yd, sd_, noise=noise.to(DEV))
     (torch.log2(lik).sum() + 0.1 * out.sum()).backward()
 
-    from licos_amd import autograd
-    s = autograd.lower_bound_ref(scales, torch.tensor([0.11]))
+    s = lower_bound_ref(scales, torch.tensor([0.11]))
     v = torch.abs(y + noise)
     c = -(2 ** -0.5)
     ref = 0.5 * torch.erfc(c * ((0.5 - v) / s)) - 0.5 * torch.erfc(c * ((-0.5 - v) / s))
-    ref = autograd.lower_bound_ref(ref, torch.tensor([1e-9]))
+    ref = lower_bound_ref(ref, torch.tensor([1e-9]))
     (torch.log2(ref).sum() + 0.1 * (y + noise).sum()).backward()
     assert torch.allclose(lik.detach().cpu(), ref.detach(), rtol=2e-5, atol=1e-9)
     for a, b in ((yd.grad.cpu(), y.grad), (sd_.grad.cpu(), scales.grad)):
@@ -284,3 +301,141 @@ def test_shipped_operating_point_codes_images():
     sym = torch.round(y - eb.medians_vec().reshape(1, -1, 1, 1)).int() - eb._offset.reshape(1, -1, 1, 1)
     esc = ((sym < 0) | (sym >= (eb._cdf_length - 2).reshape(1, -1, 1, 1))).float().mean()
     assert float(esc) < 1e-3, float(esc)
+
+
+@pytest.mark.parametrize("filters,form", [((3, 3, 3, 3), "plain"), ((1, 1, 3, 3), "plain"), ((13, 13, 3, 3), "plain"),
+                                          ((3, 3, 3, 3), "signflip"), ((5, 2, 4), "plain")])
+def test_entropy_bottleneck_backward_kernel(filters, form):
+    """licos_eb_likelihood_bwd (per-channel MLP at v -+ 1/2, analytic backward, in-kernel reductions over the batch,
+    LowerBound gradient rule) against torch autograd of CompressAI's definition on the CPU - for the three filter tuples
+    LICOS instantiates (model_utils.py:25-29), the sign-flip likelihood form and a generic shape."""
+    import torch.nn.functional as F
+    c, b, h, w = 7, 5, 9, 11  # 495 elements per channel: one slice, ragged last wave
+    torch.manual_seed(len(filters) + filters[0])
+    eb = licos_amd.EntropyBottleneck(c, filters=filters, likelihood_form=form)
+    with torch.no_grad():
+        for p in list(eb.matrices) + list(eb.biases) + list(eb.factors):
+            p.add_(0.3 * torch.randn_like(p))
+    eb = eb.to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = 4.0 * torch.randn(b, c, h, w, generator=g)
+    x[0, 0, 0, :4] = torch.tensor([60.0, -60.0, 45.0, -45.0])  # far tails: likelihood at the 1e-9 bound
+    noise = torch.rand(b, c, h, w, generator=g) - 0.5
+    wgt = torch.randn(b, c, h, w, generator=g)                 # random upstream gradient, both signs
+    xd = x.to(DEV).requires_grad_(True)
+    out, lik = eb(xd, noise=noise.to(DEV))
+    ((wgt.to(DEV) * lik).sum() + 0.1 * out.sum()).backward()
+    # CPU reference
+    params = [p.detach().cpu().clone().requires_grad_(True) for p in list(eb.matrices) + list(eb.biases) + list(eb.factors)]
+    nl = len(filters) + 1
+    xr = x.clone().requires_grad_(True)
+    outs = xr + noise
+    v = outs.transpose(0, 1).reshape(c, 1, -1)
+
+    def logits(t):
+        for i in range(nl):
+            t = torch.matmul(F.softplus(params[i]), t) + params[nl + i]
+            if i < nl - 1:
+                t = t + torch.tanh(params[2 * nl + i]) * torch.tanh(t)
+        return t
+
+    lo, up = logits(v - 0.5), logits(v + 0.5)
+    if form == "plain":
+        ref = torch.sigmoid(up) - torch.sigmoid(lo)
+    else:
+        sign = -torch.sign(lo + up).detach()
+        ref = torch.abs(torch.sigmoid(sign * up) - torch.sigmoid(sign * lo))
+    ref = lower_bound_ref(ref, torch.tensor([1e-9]))
+    ref = ref.reshape(c, b, h, w).transpose(0, 1)
+    ((wgt * ref).sum() + 0.1 * outs.sum()).backward()
+    # (far positive tail, plain form: sigmoid(up) - sigmoid(lo) cancels to fp32 noise ~6e-8 on either side)
+    assert bool(((lik.detach().cpu() - ref.detach()).abs() <= 2e-5 * ref.detach() + 3e-7).all())
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 2e-4 * float(xr.grad.abs().max())
+    for p, r in zip(list(eb.matrices) + list(eb.biases) + list(eb.factors), params):
+        assert p.grad is not None and p.grad.shape == r.grad.shape
+        assert float((p.grad.cpu() - r.grad).abs().max()) <= 3e-4 * float(r.grad.abs().max()) + 1e-7
+
+
+def test_entropy_bottleneck_backward_slices_are_deterministic():
+    """Many elements per channel -> several slices per channel; two runs give bit-identical gradients."""
+    eb = licos_amd.EntropyBottleneck(192, filters=(3, 3, 3, 3)).to(DEV).train()
+    g = torch.Generator().manual_seed(0)
+    x = (3.0 * torch.randn(16, 192, 16, 16, generator=g)).to(DEV)
+    noise = (torch.rand(16, 192, 16, 16, generator=g) - 0.5).to(DEV)
+    grads = []
+    for _ in range(2):
+        eb.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        _, lik = eb(xd, noise=noise)
+        torch.log2(lik).sum().backward()
+        grads.append([xd.grad.clone()] + [p.grad.clone() for p in eb.parameters() if p.grad is not None])
+    assert len(grads[0]) > 10 and all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_relu_and_abs_masks_in_the_conv_backward(transposed):
+    """The hyper transforms' fused ReLU (h_a, h_s) and |y| input (h_a[0]): HIP forward and backward against torch autograd."""
+    import torch.nn.functional as F
+    from licos_amd import autograd
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 24, 10, 14, generator=g)
+    w = 0.1 * torch.randn(24, 16, 5, 5, generator=g) if transposed else 0.1 * torch.randn(16, 24, 5, 5, generator=g)
+    b = torch.randn(16, generator=g)
+    xs = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    xd = [t.clone().to(DEV).requires_grad_(True) for t in (x, w, b)]
+    if transposed:
+        ref = F.relu(F.conv_transpose2d(xs[0], xs[1], xs[2], stride=2, padding=2, output_padding=1))
+        out = autograd.DeconvHip.apply(xd[0], xd[1], xd[2], 2, 2, 1, True)
+    else:
+        ref = F.relu(F.conv2d(torch.abs(xs[0]), xs[1], xs[2], stride=2, padding=2))
+        out = autograd.ConvHip.apply(xd[0], xd[1], xd[2], 2, 2, True, True)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    (out * up.to(DEV)).sum().backward()
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 2e-5 * float(ref.abs().max())
+    for a, r in zip(xd, xs):
+        assert float((a.grad.cpu() - r.grad).abs().max()) <= 5e-5 * float(r.grad.abs().max()), a.shape
+
+
+def test_conv_backward_with_odd_height_and_even_width():
+    """dgrad's output padding is per axis (an odd H with an even W used to lose the last column's gradient)."""
+    import torch.nn.functional as F
+    from licos_amd import autograd
+    g = torch.Generator().manual_seed(5)
+    for h, w in ((9, 12), (12, 9), (9, 9), (12, 12)):
+        x = torch.randn(2, 8, h, w, generator=g)
+        wt = 0.1 * torch.randn(6, 8, 5, 5, generator=g)
+        xr, xd = x.clone().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
+        F.conv2d(xr, wt, None, stride=2, padding=2).square().sum().backward()
+        autograd.ConvHip.apply(xd, wt.to(DEV), None, 2, 2).square().sum().backward()
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max()), (h, w)
+
+
+def test_config4_train_step_gradients_at_full_size():
+    """cfg/raw_merged.toml's step itself - 16 patches of 13 x 256 x 256 (channel 12 zero) - every parameter gradient
+    against the oracle under CPU autograd (BASELINE configs[3]'s per-rank workload)."""
+    import os
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd = om.perturb_state(om.make_factorized_state(13, quality=1, seed=42), seed=17, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = om.synthetic_tiles(16, 13, 256, seed=9, kind="s2-merged")
+    g = torch.Generator().manual_seed(2)
+    noise = torch.rand(16, 192, 16, 16, generator=g) - 0.5
+    res = licos_amd.RateDistortionLoss(lmbda=1e-2)(net(x.to(DEV), noise=noise.to(DEV)), x.to(DEV))
+    res["loss"].backward()
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and "bound" not in k
+                  and "pedestal" not in k and "target" not in k else v) for k, v in sd.items()}
+    ref = om.rate_distortion_loss(om.forward(x, ref_sd, training=True, noise=noise), x, 1e-2)
+    ref["loss"].backward()
+    assert abs(float(res["loss"].detach()) - float(ref["loss"].detach())) < 1e-4 * abs(float(ref["loss"].detach()))
+    checked = 0
+    for name, p in net.named_parameters():
+        rg = ref_sd[name].grad
+        if rg is None:
+            continue
+        err = float((p.grad.cpu() - rg).abs().max() / rg.abs().max().clamp_min(1e-20))
+        assert err < 2e-3, (name, err)
+        checked += 1
+    assert checked >= 40

@@ -273,6 +273,7 @@ int mfma_dispatch_conv(const MfmaArgs &a, int MT, int epi, int width, hipStream_
 int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv8.hip; 1 = not applicable
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s);
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_deconv8.hip; 1 = not applicable
+int mfma_try_conv3x3_tiles(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv3x3t.hip; 1 = not applicable
 bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv);
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 

@@ -179,6 +179,8 @@ static int dispatch_tile(const MfmaArgs &a, int width, hipStream_t s) {
 }
 
 int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStream_t s) {
+  const int rc3 = mfma_try_conv3x3_tiles(a, MT, epi, s);  // first analysis stage: resident weights, a run of tiles per workgroup
+  if (rc3 != 1) return rc3;
   const int rc8 = mfma_try_deconv8(a, MT, epi, s);  // 8-wave form for wide maps and 128 output channels
   if (rc8 != 1) return rc8;
   if (MT == 1 && epi == EPI_NONE) return dispatch_tile<1, EPI_NONE>(a, width, s);

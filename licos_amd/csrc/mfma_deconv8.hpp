@@ -1,0 +1,154 @@
+// Shared by the 8-wave tile kernels (mfma_deconv8.hip: transposed conv, four phases per workgroup; mfma_conv3x3t.hip:
+// 3x3 stride-1 conv with resident weights, several tiles per workgroup): tile geometry, the K step of one cin chunk and
+// the (I)GDN / pack / store epilogue.
+#pragma once
+#include "mfma_common.hpp"
+
+// LICOS_ABL (dev builds via tools/ab_build.sh, never the product): timing ablations.
+//   1 no LDS-DMA inside the K loop   2 no (I)GDN arithmetic in the epilogue   3 no stores   4 no MFMAs in the K loop
+#ifndef LICOS_ABL
+#define LICOS_ABL 0
+#endif
+
+namespace licos {
+
+template <int MT>
+struct Deconv8Geom {
+  static constexpr int TH = 16, TW = 32, NT = 2;
+  static constexpr int RS = 36;                       // patch row stride in granules (34 used)
+  static constexpr int PH = TH + 2;
+  static constexpr int HALF = PH * RS;                // 648
+  static constexpr int PATCH_GRAN = 2 * HALF;         // 1296
+  static constexpr int PQ = (PATCH_GRAN + 63) / 64;   // 21 wave-wide pieces
+  static constexpr int PATCH_PAD = PQ * 64;
+  static constexpr int W_GRAN_MAX = 9 * MT * 64;      // all taps of the largest phase, one cin chunk
+  static constexpr int GAMMA_GRAN = MT * MT * 2 * 64;
+  static constexpr int KLOOP_GRAN = 2 * PATCH_PAD + 2 * W_GRAN_MAX;
+  static constexpr int NPP = (PQ + 7) / 8, NWP = (9 * MT + 7) / 8, NGP = (GAMMA_GRAN / 64 + 7) / 8;  // pieces per wave
+};
+
+// one cin chunk of one phase: NKY x NKX taps x MT A fragments, each against the NT pixel tiles of the wave.  The LDS
+// reads run TWO items (one item = one A fragment = NT MFMAs) ahead of their use, pinned by sched_group_barrier: a
+// ds_read_b128 takes longer to come back than the NT MFMAs of one item take to issue.
+template <int MT, int NT, int NKY, int NKX, int RS, class Mid>
+__device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8 *s_patch, const half8 *s_w,
+                                              const int (&base)[NT], int lane, Mid &&mid) {
+  constexpr int NTAP = NKY * NKX, NI = NTAP * MT;
+  static_assert(MT >= 2, "the B fragments of the next tap are requested two items before its first use");
+  // tap t = iky * NKX + ikx reads the patch at (dy, dx) = (1 - iky, 1 - ikx) (see mfma_deconv.hip)
+  half8 a_cur = s_w[lane], a_nxt = s_w[64 + lane], b_cur[NT], b_nxt[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = b_cur[nt] = s_patch[base[nt] + RS + 1];
+  static_for<NI>([&](auto itc) {
+    constexpr int it = decltype(itc)::value, mt = it % MT, tap = it / MT;
+    constexpr bool more_a = it + 2 < NI, more_b = (mt == MT - 2) && (tap + 1 < NTAP);
+    constexpr int iky_n = (tap + 1) / NKX, ikx_n = (tap + 1) % NKX;
+    if (it == NI / 2) mid();  // half-way hook (the younger half of the waves requests its operands here)
+    half8 a_nn = a_nxt;
+    if (more_a) a_nn = s_w[(it + 2) * 64 + lane];
+    if (more_b) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = s_patch[base[nt] + (1 - iky_n) * RS + (1 - ikx_n)];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, b_cur[nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, (more_a ? 1 : 0) + (more_b ? NT : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    a_cur = a_nxt;
+    a_nxt = a_nn;
+    if (mt == MT - 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+    }
+  });
+}
+
+// ---- epilogue of one accumulator set: (I)GDN per pixel tile (squares converted once), fp16 pack, 16-byte stores ----
+// pix[nt]: index of the lane's output pixel inside the image's [Ho * Wo] plane, or -1 (outside the map: nothing stored).
+// y_img: the image's first output element; a 16-channel chunk of the image is plane_px * 16 halfs.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16x8 *s_gamma, const float *s_beta, _Float16 *y_img,
+                                               size_t plane_px, int Cout16, const long (&pix)[NT], int lane) {
+  constexpr bool NORM = (EPI == EPI_GDN || EPI == EPI_IGDN) && LICOS_ABL != 2;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bf16x8 sq[MT][2];
+    if (NORM) {
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = acc[jt][nt][8 * s + e];
+            sq[jt][s][e] = (__bf16)(v * v);
+          }
+    }
+    const bool live = pix[nt] >= 0;
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+      f32x16 scale;
+      if (NORM) {
+        f32x16 norm;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4 *>(s_beta + 32 * it + 8 * g + 4 * h);
+          norm[4 * g + 0] = bv.x;
+          norm[4 * g + 1] = bv.y;
+          norm[4 * g + 2] = bv.z;
+          norm[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            norm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_gamma[((it * MT + jt) * 2 + s) * 64 + lane], sq[jt][s], norm, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          scale[q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[q]) : __builtin_amdgcn_sqrtf(norm[q]);
+      }
+      // a lane holds channels {0-3, 8-11} (+4 for the upper half-wave) of each 16-channel chunk; one
+      // v_permlane32_swap per dword hands the lower lane channels 0-7 and the upper lane 8-15: one 16-byte store each
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        unsigned lo[2], hi[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          float v0[2], v1[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            v0[e] = acc[it][nt][8 * gp + 2 * d + e];
+            v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
+            if (NORM) {
+              v0[e] *= scale[8 * gp + 2 * d + e];
+              v1[e] *= scale[8 * gp + 4 + 2 * d + e];
+            }
+            if (EPI == EPI_RELU) {
+              v0[e] = fmaxf(v0[e], 0.f);
+              v1[e] = fmaxf(v1[e], 0.f);
+            }
+          }
+          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+          half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
+          lo[d] = __builtin_bit_cast(unsigned, p0);
+          hi[d] = __builtin_bit_cast(unsigned, p1);
+          const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+          lo[d] = sw[0];
+          hi[d] = sw[1];
+        }
+        const int chunk = 2 * it + gp;
+        if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
+          _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
+          *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+        }
+      }
+      // one 32-channel tile at a time: letting the scheduler interleave the four norm chains costs 48 more live
+      // registers than the kernel has, and a spill reload is a vmcnt event (see the counted waits of the callers)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+}  // namespace licos

@@ -89,7 +89,10 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
 #endif
   const unsigned m0v = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v));  // m0 is a reserved register the compiler only writes right before its own uses
+  unsigned keep;  // M0 is compiler-reserved: written and restored inside the one statement that uses it
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(m0v));
 }
 
 // Transposed conv (mfma_deconv.hip): a workgroup owns ONE output phase (py, px) of a TH x TW input tile.  The

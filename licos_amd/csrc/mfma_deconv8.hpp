@@ -9,6 +9,13 @@
 #ifndef LICOS_ABL
 #define LICOS_ABL 0
 #endif
+// Output stores of the tile kernels carry sc1: written through and NOT kept in the XCD's L2 (MI355X_MICROARCH.md, "stores
+// of each flavour").  A stage's output is gigabytes that nothing re-reads before it has left a 4 MB L2 anyway, but kept
+// there it evicts the input patches the transposed conv re-reads once per phase: with plain stores that kernel fetched
+// 4.1x its input from HBM (profiles/r02_pmc_traffic_deconv_s4_plain_stores.json).  LICOS_STORE_SC1=0: A/B builds only.
+#ifndef LICOS_STORE_SC1
+#define LICOS_STORE_SC1 1
+#endif
 
 namespace licos {
 
@@ -141,7 +148,15 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
         const int chunk = 2 * it + gp;
         if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
           _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
-          *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+          if (LICOS_STORE_SC1) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 val = {lo[0], lo[1], hi[0], hi[1]};
+            // (the s_nop covers the ISA's manual wait state between a store of more than 64 bits and the next write of
+            // its data registers, which the compiler cannot see through the asm)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+          } else {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+          }
         }
       }
       // one 32-channel tile at a time: letting the scheduler interleave the four norm chains costs 48 more live

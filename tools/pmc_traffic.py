@@ -14,7 +14,8 @@ def collect(path, counter, needle):
     rows = []
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+            name = r["Kernel_Name"].replace("void ", "").replace("licos::", "")
+            if r["Counter_Name"] == counter and name.startswith(needle):  # "conv..." must not match "deconv..."
                 rows.append((int(r["Grid_Size"]), float(r["Counter_Value"]), r["Kernel_Name"]))
     if not rows:
         raise SystemExit(f"no {counter} rows for kernels matching {needle!r} in {path}")

@@ -51,6 +51,9 @@ def parse_args():
                     help="trained: licos_amd/weights (the repo's own training recipe, tools/train_weights.py) when present")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (skip the measurement grid)")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="also time the federated average through liblicos_hip.so's own RCCL communicator "
+                         "(licos_allreduce_weighted); off by default: it has only ever run with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -390,6 +393,25 @@ def main():
                "frac_of_7x153": round(busbw / XGMI_PEAK_GBPS, 4), "backend": args.backend,
                "nccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))},
                "what": "scale + all-reduce(SUM) + normalise of the whole floating state, per averaging step"}
+        if args.native_rccl and args.backend == "nccl":
+            try:
+                comm = federation.NativeComm()
+                for _ in range(3):
+                    federation.weighted_average_(fs, 1.0 / world, native=comm)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    federation.weighted_average_(fs, 1.0 / world, native=comm)
+                fence()
+                nt = torch.tensor([(time.perf_counter() - t1) / reps], device=dev, dtype=torch.float64)
+                dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+                nb = 2 * (world - 1) / world * nbytes_bucket / float(nt.item()) / 1e9
+                fed["native_rccl"] = {"ms": round(1e3 * float(nt.item()), 4), "busbw_GBps": round(nb, 2),
+                                      "frac_of_7x153": round(nb / XGMI_PEAK_GBPS, 4),
+                                      "what": "licos_allreduce_weighted: scale + ncclAllReduce + normalise as one C-ABI call"}
+                comm.close()
+            except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
+                fed["native_rccl"] = {"error": str(e)[:300]}
         # config 4: the training step of cfg/raw_merged.toml on every rank, then the average of its state
         tr, tnet = train_step_ms(dev, steps=5, world=world)
         tfs = federation.FlatState(tnet)

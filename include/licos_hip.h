@@ -183,6 +183,12 @@ int licos_resample_bilinear_f32(const float *src, float *dst, long planes, int H
  * ride the batched tile codec instead of one 4.5-M-symbol stream. */
 int licos_tile_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, void *stream);
 int licos_untile_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, void *stream);
+/* The same with overlapping tiles: tile (iy, ix) starts at (iy*S - margin, ix*S - margin), S = T - 2*margin, zero outside
+ * the image; the inverse writes back only each tile's central S x S pixels.  There are ceil(H/S) x ceil(W/S) tiles per
+ * image.  The reference codes whole images (eval_script.py:138-165) and so has no tile seams; a margin of a few latent
+ * cells (e.g. 32) keeps the transforms' zero padding at tile borders out of the reconstruction. */
+int licos_tile_overlap_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, int margin, void *stream);
+int licos_untile_overlap_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, int margin, void *stream);
 
 /* mean-squared-error numerator: sum over all elements of (a-b)^2 into *out (double, zeroed by caller);
  * /root/reference/eval_utils.py:145-156, RateDistortionLoss mse term.  clamp01 != 0 clamps `a` first. */
@@ -332,6 +338,17 @@ int licos_nchw_f32_split_bm8(const float *x, void *y_hi, void *y_lo, int B, int 
 int licos_wgrad5x5s2_strips(int Cs, int Cl, int Hs);
 int licos_wgrad5x5s2_f16(const void *small_bm8, const void *large_bm8, float *scratch, float *dw, int Cs, int Cl, int nbc, int Hs,
                          int Ws, int Hl, int Wl, int scale_down, void *stream);
+
+/* --------------------------------------------- federated weight average over RCCL / xGMI
+ * Replaces the file-and-lock blend of /root/reference/licos/federation_utils.py:27-85 (and the mpi4py scalars of
+ * licos/main.py:96-107 stay with the host framework).  One communicator per process: rank 0 makes the 128-byte id,
+ * the host framework hands it to every rank (any channel: torch.distributed's store, MPI, a file), every rank calls
+ * licos_comm_init with its device current.  licos_allreduce_weighted, in place on `bucket` (n floats, the LAST one
+ * reserved): bucket[:n-1] <- sum_r coef_r * bucket_r[:n-1] / sum_r coef_r, all on `stream`, nothing synchronised. */
+int licos_comm_unique_id(void *out128);
+int licos_comm_init(void **comm, int nranks, int rank, const void *id128);
+int licos_comm_destroy(void *comm);
+int licos_allreduce_weighted(float *bucket, long n, float coef, void *comm, void *stream);
 
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1

@@ -5,10 +5,16 @@ Checkpoints: the dict LICOS writes - {"batch_idx", "state_dict", "loss", "local_
 (/root/reference/eval_script.py:68-72: torch.load -> load_state_dict(ckpt["state_dict"]) -> update()).  State-dict keys
 are CompressAI's, so files move between the two implementations.
 
-Bit streams: a length-prefixed container for compress() output, following the layout of CompressAI's
-examples/codec.py (big-endian uint32 fields: shape, number of string lists, then per string its length and bytes),
-extended with a leading batch count because LICOS codes batches of tiles.  CompressAI is absent here, so the
-container is self-consistent rather than verified against that tool."""
+Bit streams, two containers:
+* ``write_image`` / ``read_image``: ONE image per record in the byte layout of CompressAI's ``examples/codec.py``
+  (``_encode_image`` / ``_decode_image``: two header bytes - model id, (metric << 4) | (quality - 1) -, the original
+  size as two big-endian uint32, then ``write_body``: latent shape (2 x uint32), the number of string lists (uint32) and
+  per list the length (uint32) and bytes of its string).  Such a file is what ``python -m compressai.utils... codec
+  decode`` style tools read for the same model and weights.  The model-id table is CompressAI's zoo order, which differs
+  between releases (``bmshj2018-factorized-relu`` was inserted at index 1); both tables are provided.  CompressAI is
+  absent from this image, so the layout is restated from its published source, not verified against the tool.
+* ``write_strings`` / ``read_strings``: a whole ``compress()`` result (a batch of tiles) in one stream: the same body
+  fields with a leading magic and batch count - a licos_amd format, because codec.py has no notion of a batch."""
 import os
 import shutil
 import struct
@@ -90,3 +96,50 @@ def read_strings(fd):
             lst.append(_read_exact(fd, n))
         strings.append(lst)
     return {"strings": strings, "shape": (h, w)}
+
+
+# ---- one image per record, CompressAI examples/codec.py layout ---------------------------------------------------
+MODEL_IDS = {  # compressai.zoo.image_models order; "legacy" = releases without the -relu variant (<= 1.2.0)
+    "legacy": {"bmshj2018-factorized": 0, "bmshj2018-hyperprior": 1, "mbt2018-mean": 2, "mbt2018": 3,
+               "cheng2020-anchor": 4, "cheng2020-attn": 5},
+    "current": {"bmshj2018-factorized": 0, "bmshj2018-factorized-relu": 1, "bmshj2018-hyperprior": 2, "mbt2018-mean": 3,
+                "mbt2018": 4, "cheng2020-anchor": 5, "cheng2020-attn": 6},
+}
+METRIC_IDS = {"mse": 0, "ms-ssim": 1}
+
+
+def write_image(fd, out, index, model, quality, original_size, metric="mse", ids="current"):
+    """Writes image `index` of a compress() result as one codec.py record; returns the number of bytes written."""
+    table = MODEL_IDS[ids]
+    if model not in table:
+        raise ValueError(f"{model!r} has no id in CompressAI's {ids} model table")
+    if not 1 <= int(quality) <= 16:
+        raise ValueError("quality must be 1..16")
+    strings, shape = out["strings"], out["shape"]
+    start = fd.tell()
+    fd.write(struct.pack(">2B", table[model], (METRIC_IDS[metric] << 4) | ((int(quality) - 1) & 0x0F)))
+    _w(fd, ">2I", int(original_size[0]), int(original_size[1]))
+    _w(fd, ">3I", int(shape[0]), int(shape[1]), len(strings))
+    for lst in strings:
+        s = bytes(lst[index])
+        _w(fd, ">I", len(s))
+        fd.write(s)
+    return fd.tell() - start
+
+
+def read_image(fd, ids="current"):
+    """Reads one codec.py record: (model, metric, quality, original_size, {"strings": [[s], ...], "shape"})."""
+    model_id, code = struct.unpack(">2B", _read_exact(fd, 2))
+    names = {v: k for k, v in MODEL_IDS[ids].items()}
+    if model_id not in names:
+        raise ValueError(f"unknown model id {model_id}")
+    metric = {v: k for k, v in METRIC_IDS.items()}.get(code >> 4)
+    if metric is None:
+        raise ValueError(f"unknown metric id {code >> 4}")
+    h, w = struct.unpack(">2I", _read_exact(fd, 8))
+    s0, s1, nl = struct.unpack(">3I", _read_exact(fd, 12))
+    strings = []
+    for _ in range(nl):
+        (n,) = struct.unpack(">I", _read_exact(fd, 4))
+        strings.append([_read_exact(fd, n)])
+    return names[model_id], metric, (code & 0x0F) + 1, (h, w), {"strings": strings, "shape": (s0, s1)}

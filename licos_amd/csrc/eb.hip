@@ -427,7 +427,10 @@ __global__ void resample_bilinear_kernel(const float *__restrict__ src, float *_
 }
 
 // dir 0: image -> tiles, 1: tiles -> image.  One thread per tile element; x fastest (coalesced both sides).
-__global__ void tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int H, int W, int T, int ny,
+// With a margin m > 0 tiles overlap: tile (iy, ix) covers image rows iy*S - m .. iy*S - m + T - 1, S = T - 2m, and only
+// its central S x S pixels are written back - every reconstructed pixel then sits >= m pixels inside the tile that
+// coded it (the transforms' zero padding at a tile border otherwise shows as a seam).
+__global__ void tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int H, int W, int T, int m, int ny,
                             int nx, long total, int dir) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int tx = (int)(e % T);
@@ -436,11 +439,12 @@ __global__ void tile_kernel(const float *__restrict__ src, float *__restrict__ d
     const long t = e / ((long)T * T * C);
     const int ix = (int)(t % nx), iy = (int)((t / nx) % ny);
     const long b = t / ((long)nx * ny);
-    const int y = iy * T + ty, x = ix * T + tx;
-    const bool in = y < H && x < W;
+    const int S = T - 2 * m;
+    const int y = iy * S - m + ty, x = ix * S - m + tx;
+    const bool in = y >= 0 && x >= 0 && y < H && x < W;
     const size_t img = (((size_t)b * C + c) * H + y) * W + x;
     if (dir == 0) dst[e] = in ? src[img] : 0.f;
-    else if (in) dst[img] = src[e];
+    else if (in && ty >= m && ty < T - m && tx >= m && tx < T - m) dst[img] = src[e];
   }
 }
 
@@ -592,22 +596,31 @@ int licos_resample_bilinear_f32(const float *src, float *dst, long planes, int H
   return LICOS_OK;
 }
 
-static int tile_launch(const float *src, float *dst, int B, int C, int H, int W, int T, int dir, void *stream) {
+static int tile_launch(const float *src, float *dst, int B, int C, int H, int W, int T, int m, int dir, void *stream) {
   LICOS_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && T > 0, "tile: bad arguments");
-  const int ny = cdiv(H, T), nx = cdiv(W, T);
+  LICOS_REQUIRE(m >= 0 && 2 * m < T, "tile: the margin must leave a positive tile core");
+  const int ny = cdiv(H, T - 2 * m), nx = cdiv(W, T - 2 * m);
   const long total = (long)B * ny * nx * C * T * T;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(tile_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, C, H, W, T, ny, nx, total, dir);
+  hipLaunchKernelGGL(tile_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, C, H, W, T, m, ny, nx, total, dir);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
 
 int licos_tile_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, void *stream) {
-  return tile_launch(img, tiles, B, C, H, W, T, 0, stream);
+  return tile_launch(img, tiles, B, C, H, W, T, 0, 0, stream);
 }
 
 int licos_untile_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, void *stream) {
-  return tile_launch(tiles, img, B, C, H, W, T, 1, stream);
+  return tile_launch(tiles, img, B, C, H, W, T, 0, 1, stream);
+}
+
+int licos_tile_overlap_f32(const float *img, float *tiles, int B, int C, int H, int W, int T, int margin, void *stream) {
+  return tile_launch(img, tiles, B, C, H, W, T, margin, 0, stream);
+}
+
+int licos_untile_overlap_f32(const float *tiles, float *img, int B, int C, int H, int W, int T, int margin, void *stream) {
+  return tile_launch(tiles, img, B, C, H, W, T, margin, 1, stream);
 }
 
 int licos_scale_f32(float *x, long n, float alpha, const float *inv_alpha_dev, void *stream) {

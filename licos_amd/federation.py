@@ -18,10 +18,12 @@ Integer buffers (the entropy coder's tables) are not averaged: blending them is 
 in exact arithmetic and a truncation hazard in floating point; ``update_central_model`` rebuilds
 them from the averaged parameters (``net.update(force=True)``) when the model carries tables.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 class FlatState:
@@ -67,9 +69,46 @@ def reference_coefficients(losses, best_losses):
     return coef
 
 
-def weighted_average_(flat_state, coef, group=None):
-    """In place: bucket <- sum_r coef_r * bucket_r / sum_r coef_r over the process group."""
+class NativeComm:
+    """An RCCL communicator owned by liblicos_hip.so (licos_comm_init): the collective of the federated average then
+    runs as ONE C-ABI call on the caller's stream (licos_allreduce_weighted: scale, all-reduce over xGMI, normalise)
+    instead of two kernels around torch.distributed's all_reduce.  The 128-byte id travels through the existing process
+    group (any backend).  Every rank of the group must construct it, with its device current."""
+
+    def __init__(self, group=None):
+        lib = _lib.load()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.licos_comm_unique_id(ctypes.cast(ident, ctypes.c_void_p)), "comm_unique_id")
+        box = [ident.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+        self._comm = ctypes.c_void_p()
+        _lib.check(lib.licos_comm_init(ctypes.byref(self._comm), world, rank, ctypes.cast(ident, ctypes.c_void_p)), "comm_init")
+        self.world, self.rank = world, rank
+
+    def allreduce_weighted_(self, flat, coef):
+        ops._dev(flat)
+        rc = _lib.load().licos_allreduce_weighted(ops._p(ops._f32(flat)), flat.numel(), float(coef), self._comm, ops._stream())
+        _lib.check(rc, "allreduce_weighted")
+        ops.touch_weights()
+        return flat
+
+    def close(self):
+        if self._comm:
+            _lib.check(_lib.load().licos_comm_destroy(self._comm), "comm_destroy")
+            self._comm = ctypes.c_void_p()
+
+
+def weighted_average_(flat_state, coef, group=None, native=None):
+    """In place: bucket <- sum_r coef_r * bucket_r / sum_r coef_r over the process group (`native`: a NativeComm -
+    the whole step as one licos_allreduce_weighted call)."""
     flat = flat_state.flat
+    if native is not None:
+        with torch.no_grad():
+            native.allreduce_weighted_(flat, coef)
+        return flat_state
     with torch.no_grad():
         flat[-1] = 1.0
         if flat.is_cuda:
@@ -98,7 +137,7 @@ def _gather_scalars(values, world, rank, device, group):
 
 
 def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_time, cfg=None, flat_state=None,
-                         group=None, uniform=False):
+                         group=None, uniform=False, native=None):
     """Collective counterpart of ``federation_utils.update_central_model`` (same leading arguments).
     Every rank of the group must call it.  Returns the FlatState (reuse it on the next call)."""
     if flat_state is None:
@@ -112,7 +151,7 @@ def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_ti
         r = dist.get_rank(group)
         vals = _gather_scalars([loss, best_loss], world, r, flat_state.flat.device, group)
         coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[r]
-    weighted_average_(flat_state, coef, group=group)
+    weighted_average_(flat_state, coef, group=group, native=native)
     # the integer coder tables are functions of the (now averaged) parameters: rebuild them when the model carries any,
     # so that neither the module nor the checkpoint written below pairs new weights with old tables
     if any(getattr(m, "_offset", None) is not None and m._offset.numel() > 0 for m in net.modules()):

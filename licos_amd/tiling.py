@@ -22,29 +22,36 @@ def dn12_to_grid8(dn, full_range=False):
     return out
 
 
-def tile(x, size=256):
-    """(B, C, H, W) -> (B*ny*nx, C, size, size), zero padded on the right/bottom; returns (tiles, geometry)."""
+def tile(x, size=256, margin=0):
+    """(B, C, H, W) -> (B*ny*nx, C, size, size); returns (tiles, geometry).  margin = 0: disjoint tiles, zero padded on
+    the right/bottom.  margin > 0: tiles overlap by 2*margin and only their central (size - 2*margin)^2 pixels are kept
+    by `untile` - the reconstruction then has no tile seams (each pixel is coded >= margin pixels inside its tile), at
+    (size / (size - 2*margin))^2 times the tiles."""
     ops._dev(x)
     b, c, h, w = x.shape
-    ny, nx = -(-h // size), -(-w // size)
+    if margin < 0 or 2 * margin >= size:
+        raise ValueError("tile: the margin must leave a positive tile core")
+    core = size - 2 * margin
+    ny, nx = -(-h // core), -(-w // core)
     tiles = torch.empty((b * ny * nx, c, size, size), device=x.device, dtype=torch.float32)
-    rc = _lib.load().licos_tile_f32(ops._p(ops._f32(x.contiguous())), ops._p(tiles), b, c, h, w, size, ops._stream())
+    rc = _lib.load().licos_tile_overlap_f32(ops._p(ops._f32(x.contiguous())), ops._p(tiles), b, c, h, w, size, margin, ops._stream())
     _lib.check(rc, "tile")
-    return tiles, (b, c, h, w, size)
+    return tiles, (b, c, h, w, size, margin)
 
 
 def untile(tiles, geometry):
     ops._dev(tiles)
-    b, c, h, w, size = geometry
+    b, c, h, w, size = geometry[:5]
+    margin = geometry[5] if len(geometry) > 5 else 0
     img = torch.empty((b, c, h, w), device=tiles.device, dtype=torch.float32)
-    rc = _lib.load().licos_untile_f32(ops._p(ops._f32(tiles.contiguous())), ops._p(img), b, c, h, w, size, ops._stream())
+    rc = _lib.load().licos_untile_overlap_f32(ops._p(ops._f32(tiles.contiguous())), ops._p(img), b, c, h, w, size, margin, ops._stream())
     _lib.check(rc, "untile")
     return img
 
 
-def compress_image(net, x, size=256):
+def compress_image(net, x, size=256, margin=0):
     """Tile-wise encode of whole images: {"strings", "shape", "geometry"}."""
-    tiles, geo = tile(x, size)
+    tiles, geo = tile(x, size, margin)
     out = net.compress(tiles)
     out["geometry"] = geo
     return out

@@ -388,6 +388,24 @@ def test_granule_tiling_and_dn_conversion():
         coded = tiling.compress_image(net, x)
         rec = tiling.decompress_image(net, coded)["x_hat"]
     assert len(coded["strings"][0]) == 6 and tuple(rec.shape) == tuple(x.shape)
+    # overlapping tiles: geometry, exact round trip of the tiling itself, and what the margin is for - away from the image
+    # border a pixel next to a tile seam is reconstructed as the whole-image codec reconstructs it
+    tiles_o, geo_o = tiling.tile(x, 128, margin=32)          # core 64: ceil(300/64) x ceil(520/64) tiles
+    assert tuple(tiles_o.shape) == (5 * 9, 1, 128, 128)
+    assert torch.equal(tiles_o[10, 0, 32:96, 32:96], x[0, 0, 64:128, 64:128])      # tile (1, 1): rows/cols 64 - 32 ...
+    assert torch.equal(tiles_o[0, 0, 32:, 32:], x[0, 0, :96, :96]) and float(tiles_o[0, 0, :32].abs().max()) == 0.0
+    assert torch.equal(tiling.untile(tiles_o, geo_o), x)
+    with pytest.raises(ValueError):
+        tiling.tile(x, 64, margin=32)
+    smooth = om.synthetic_tiles(1, 1, 512, seed=5, kind="s2")[:, :, :304, :512].contiguous().to(DEV)
+    with torch.no_grad():
+        whole = net(smooth)["x_hat"].clamp(0, 1)
+        plain = tiling.decompress_image(net, tiling.compress_image(net, smooth, 128))["x_hat"]
+        lapped = tiling.decompress_image(net, tiling.compress_image(net, smooth, 128, margin=32))["x_hat"]
+    inner = (slice(None), slice(None), slice(64, 240), slice(64, 448))
+    e_plain = float((plain[inner] - whole[inner]).abs().max())
+    e_lapped = float((lapped[inner] - whole[inner]).abs().max())
+    assert e_lapped < 0.5 * e_plain, (e_plain, e_lapped)     # seams of disjoint tiles show; with the margin they do not
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])

@@ -181,3 +181,44 @@ def test_forward_after_two_rank_weighted_average(tmp_path):
     assert torch.equal(res[0]["x_hat"], res[1]["x_hat"])
     assert res[0]["strings16"] == res[1]["strings16"]
     assert rel_err(res[0]["after"]["g_a.2.weight"], res[0]["before"]["g_a.2.weight"]) > 1e-2
+
+
+def _native_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # only carries the communicator id
+    try:
+        net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+        sd = om.perturb_state(om.make_factorized_state(3, 1, seed=3), seed=3)
+        net.load_state_dict(sd)
+        net = net.to(DEV).eval()
+        net.update(force=True)
+        x = om.synthetic_tiles(1, 3, 64, seed=2)
+        with torch.no_grad():
+            net.set_precision("fp16")
+            y0 = net.g_a(x.to(DEV))
+        before = _cpu_state(net)
+        comm = federation.NativeComm()
+        fs = federation.update_central_model(rank, DEV, 1, net, 0.8, 0.5, 0.0, native=comm)
+        with torch.no_grad():
+            y1 = net.g_a(x.to(DEV))
+        comm.close()
+        torch.save({"before": before, "after": _cpu_state(net), "coef": float(fs.flat[-1]), "dy": rel_err(y1, y0)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_export_single_rank(tmp_path):
+    """licos_comm_* / licos_allreduce_weighted through a real RCCL communicator.  One GPU here, so one
+    rank: the all-reduce is the identity and the blend must return the model unchanged (to fp32 rounding of x * c / c),
+    with the coefficient in the bucket's last element and the caches invalidated.  More ranks: the driver's SCALE run
+    (bench.py reports `native_rccl`)."""
+    out = str(tmp_path / "n.pt")
+    mp.spawn(_native_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=False)
+    assert abs(r["coef"] - 1.0) < 1e-6 and r["dy"] < 1e-5
+    for k, v in r["before"].items():
+        if v.dtype == torch.float32:
+            assert torch.allclose(r["after"][k], v, rtol=1e-6, atol=1e-12), k

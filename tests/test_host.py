@@ -226,3 +226,35 @@ def test_checkpoint_dict_layout(tmp_path):
     back = torch.load(expect, weights_only=False)
     assert back["batch_idx"] == 7 and back["local_time"] == 12.5
     assert torch.equal(back["state_dict"]["w"], net.w.detach())
+
+
+def test_codec_py_record_layout():
+    """checkpoint.write_image / read_image: CompressAI examples/codec.py's per-image record, byte for byte as restated
+    from its source (header bytes, big-endian uint32 fields), for a factorized (1 string list) and a hyperprior (2) result."""
+    import io
+    import struct
+    from licos_amd import checkpoint
+    out = {"strings": [[b"abcd" * 3, b"xy" * 4], [b"zz" * 2, b""]], "shape": (4, 6)}
+    buf = io.BytesIO()
+    n = checkpoint.write_image(buf, out, 1, "bmshj2018-hyperprior", 5, (64, 96))
+    raw = buf.getvalue()
+    assert n == len(raw)
+    assert raw[:2] == bytes([2, (0 << 4) | 4])                         # model id (current table), metric mse, quality 5
+    assert struct.unpack(">2I", raw[2:10]) == (64, 96)                 # original size
+    assert struct.unpack(">3I", raw[10:22]) == (4, 6, 2)               # latent shape, number of string lists
+    assert struct.unpack(">I", raw[22:26]) == (8,) and raw[26:34] == b"xy" * 4
+    assert struct.unpack(">I", raw[34:38]) == (0,) and len(raw) == 38
+    buf.seek(0)
+    model, metric, quality, size, back = checkpoint.read_image(buf)
+    assert (model, metric, quality, size) == ("bmshj2018-hyperprior", "mse", 5, (64, 96))
+    assert back == {"strings": [[b"xy" * 4], [b""]], "shape": (4, 6)}
+    # the older zoo order (no -relu variant): hyperprior is id 1
+    b2 = io.BytesIO()
+    checkpoint.write_image(b2, out, 0, "bmshj2018-hyperprior", 1, (64, 96), ids="legacy")
+    assert b2.getvalue()[0] == 1
+    b2.seek(0)
+    assert checkpoint.read_image(b2, ids="legacy")[0] == "bmshj2018-hyperprior"
+    with pytest.raises(ValueError):
+        checkpoint.write_image(io.BytesIO(), out, 0, "bmshj2018-factorized-relu", 1, (64, 96), ids="legacy")
+    with pytest.raises(ValueError):
+        checkpoint.read_image(io.BytesIO(raw[:20]))

@@ -214,6 +214,7 @@ def extras(args, net, x, dev):
                                                  "bytes": sum(len(s) for s in coded["strings"][0])}}
         del n2, xb
     out["configs"] = configs
+    torch.cuda.empty_cache()
     out["train_step"] = train_step_ms(dev, steps=10)[0]
     return out
 

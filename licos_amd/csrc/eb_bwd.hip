@@ -267,8 +267,8 @@ extern "C" {
 
 int licos_eb_likelihood_bwd_slices(int B, int HW) {
   const long n = (long)B * HW;
-  long s = n / 1024;  // >= 16 wave-iterations per slice
-  return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
+  long s = n / 256;  // >= 4 wave-iterations per slice; 192 channels x 16 slices fill the chip's 2048 single-wave slots
+  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
 int licos_eb_likelihood_bwd(const float *v, const float *g_lik, const float *packed, const int *filters, int nfilt, float bound,

@@ -30,7 +30,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_TILE_A3 = 2 * 1677721600  # g_a[2] = g_s[4]: 128->128 5x5 s2 between 128^2 and 64^2
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16 MFMA (MI355X_MICROARCH.md chip table)
 XGMI_PEAK_GBPS = 7 * 153.0         # per GPU: 7 links x ~153 GB/s
 

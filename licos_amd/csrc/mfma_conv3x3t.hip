@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_tiles_kernel(MfmaArgs a, int
   bool counted = false;  // the youngest NSTORE operations of this wave are the previous tile's stores
   for (int t = 0; t < t_count; ++t) {
     const int cur = t & 1;
-    deconv8_chunk<MT, NT, 3, 3, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_w, base, lane, []() {});
+    deconv8_chunk<MT, NT, 3, 3, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_w, base, lane);
     // the patch of tile t+1 (requested before the previous epilogue, or above) has landed: everything older than
     // this wave's last NSTORE operations is complete
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");

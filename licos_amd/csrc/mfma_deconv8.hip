@@ -17,10 +17,6 @@
 
 #include "mfma_deconv8.hpp"
 
-#ifndef LICOS_STAGGER
-#define LICOS_STAGGER 0
-#endif
-
 namespace licos {
 
 template <int MT, int EPI>
@@ -150,17 +146,10 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
     constexpr int NKY = decltype(nky_c)::value, NKX = decltype(nkx_c)::value;
     for (int cc = 0; cc < a.Cin16; ++cc) {
       const bool counted = requested && all_live;
-      // waves 0-3 request the next step's operands at the start of the step, waves 4-7 (their SIMD partners) half-way
-      // through it: a request costs its wave ~60 issue cycles per piece, which the partner's MFMAs cover only if the
-      // two are not doing it at the same moment
-      const bool want = !requested && LICOS_ABL != 1;
-      const bool late = LICOS_STAGGER && wave >= 4;
-      if (want && !late) dma_step(phase, cc + 1, cur ^ 1);
+      if (!requested && LICOS_ABL != 1) dma_step(phase, cc + 1, cur ^ 1);  // the next step's operands land under this step's MFMAs
       requested = false;
       if (LICOS_ABL != 4)
-        deconv8_chunk<MT, NT, NKY, NKX, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_wbuf + cur * G::W_GRAN_MAX, base, lane,
-                                               [&]() { if (want && late) dma_step(phase, cc + 1, cur ^ 1); });
-      else if (want && late) dma_step(phase, cc + 1, cur ^ 1);
+        deconv8_chunk<MT, NT, NKY, NKX, G::RS>(acc, s_pbuf + cur * G::PATCH_PAD, s_wbuf + cur * G::W_GRAN_MAX, base, lane);
       // my DMA pieces have landed; after the barrier so have everyone's, and every wave is done reading the buffers
       // the next step overwrites
       if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");

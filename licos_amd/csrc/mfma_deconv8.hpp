@@ -37,9 +37,9 @@ struct Deconv8Geom {
 // one cin chunk of one phase: NKY x NKX taps x MT A fragments, each against the NT pixel tiles of the wave.  The LDS
 // reads run TWO items (one item = one A fragment = NT MFMAs) ahead of their use, pinned by sched_group_barrier: a
 // ds_read_b128 takes longer to come back than the NT MFMAs of one item take to issue.
-template <int MT, int NT, int NKY, int NKX, int RS, class Mid>
+template <int MT, int NT, int NKY, int NKX, int RS>
 __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8 *s_patch, const half8 *s_w,
-                                              const int (&base)[NT], int lane, Mid &&mid) {
+                                              const int (&base)[NT], int lane) {
   constexpr int NTAP = NKY * NKX, NI = NTAP * MT;
   static_assert(MT >= 2, "the B fragments of the next tap are requested two items before its first use");
   // tap t = iky * NKX + ikx reads the patch at (dy, dx) = (1 - iky, 1 - ikx) (see mfma_deconv.hip)
@@ -50,7 +50,6 @@ __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8
     constexpr int it = decltype(itc)::value, mt = it % MT, tap = it / MT;
     constexpr bool more_a = it + 2 < NI, more_b = (mt == MT - 2) && (tap + 1 < NTAP);
     constexpr int iky_n = (tap + 1) / NKX, ikx_n = (tap + 1) % NKX;
-    if (it == NI / 2) mid();  // half-way hook (the younger half of the waves requests its operands here)
     half8 a_nn = a_nxt;
     if (more_a) a_nn = s_w[(it + 2) * 64 + lane];
     if (more_b) {

@@ -7,11 +7,14 @@ from licos_amd.layers import GDN, deconv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+plain = len(sys.argv) > 4 and sys.argv[4] == "nogdn"  # no (I)GDN epilogue: K loop + stores only
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 # the probed stage sits between a producer and a consumer of its own kind, as in g_s (x-split layouts on both sides)
-seq = nn.Sequential(deconv(128, 128), GDN(128, inverse=True), deconv(128, 128), GDN(128, inverse=True),
-                    deconv(128, 3)).to(dev).eval()
+mods = [deconv(128, 128), GDN(128, inverse=True), deconv(128, 128), GDN(128, inverse=True), deconv(128, 3)]
+if plain:
+    mods = [m for m in mods if not isinstance(m, GDN)]
+seq = nn.Sequential(*mods).to(dev).eval()
 x = torch.randn(B, 8, hw // 2, hw // 2, 16, device=dev).half()
 with torch.no_grad():
     for it in range(2 + reps):

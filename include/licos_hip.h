@@ -95,6 +95,11 @@ int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff,
  * Conv2d: inp = x, g = dy.  ConvTranspose2d: inp = dy, g = x (dw then has the [Cin][Cout][K][K] layout). dw is overwritten. */
 int licos_conv2d_wgrad_f32(const float *inp /*[B][Ci][H][W]*/, const float *g /*[B][Co][Ho][Wo]*/, float *dw, int B,
                            int Ci, int H, int W, int Co, int K, int stride, int pad, int square_input, void *stream);
+/* The GDN gamma gradient (the 1x1, square_input case above) for 128 channels on the matrix cores:
+ * dgamma_eff[i][j] = sum_{b,p} t[b][i][p] * x[b][j][p]^2, fp32-grade through the three-pass fp16 split, partial matrices per
+ * workgroup added in a fixed order (bit-reproducible).  scratch: licos_gdn_gamma_grad_parts(B, HW) * 128 * 128 floats. */
+int licos_gdn_gamma_grad_parts(int B, long HW);
+int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream);
 int licos_bias_grad_f32(const float *dy /*[B][C][HW]*/, float *db /*[C]*/, int B, int C, long HW, void *stream);
 /* GDN backward: dx, and t = dL/dnorm (dgamma_eff = licos_conv2d_wgrad_f32(x, t, K=1, square_input=1), dbeta_eff =
  * licos_bias_grad_f32(t)); gamma_t_scratch: C*C floats. */

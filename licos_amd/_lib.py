@@ -24,6 +24,8 @@ SIGNATURES = {
     "licos_gdn_reparam_f32": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _i, _vp]),
     "licos_gdn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_gdn_gamma_grad_parts": (_i, [_i, _l]),
+    "licos_gdn_gamma_grad_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
     "licos_bias_grad_f32": (_i, [_vp, _vp, _i, _i, _l, _vp]),
     "licos_gdn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_reparam_bwd_f32": (_i, [_vp, _vp, _f, _vp, _l, _vp]),

@@ -258,6 +258,14 @@ def conv2d_wgrad_f32(inp, g, ci, co, k, stride, pad, square_input=False):
     b, _, h, w = inp.shape
     if WGRAD_MFMA and FP32_MFMA and (k, stride, pad) == (5, 2, 2) and not square_input:
         return _wgrad5x5s2_x3(inp, g, ci, co)
+    if GDN_MFMA and square_input and (k, stride, pad) == (1, 1, 0) and ci == co == 128 and (h * w) % 4 == 0:
+        # the GDN gamma gradient: a 128 x 128 product over all pixels of the batch, on the matrix cores
+        lib = _lib.load()
+        scratch = torch.empty(lib.licos_gdn_gamma_grad_parts(b, h * w) * 128 * 128, device=inp.device, dtype=torch.float32)
+        dw = torch.empty((co, ci, 1, 1), device=inp.device, dtype=torch.float32)
+        rc = lib.licos_gdn_gamma_grad_f32(_p(_f32(g.contiguous())), _p(_f32(inp.contiguous())), _p(scratch), _p(dw), b, 128, h * w, _stream())
+        _lib.check(rc, "gdn_gamma_grad_f32")
+        return dw
     dw = torch.empty((co, ci, k, k), device=inp.device, dtype=torch.float32)
     rc = _lib.load().licos_conv2d_wgrad_f32(_p(_f32(inp)), _p(_f32(g)), _p(dw), b, ci, h, w, co, k, stride, pad,
                                             int(square_input), _stream())

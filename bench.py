@@ -77,13 +77,16 @@ def spawn_workers(args):
     return max(abs(rc) for rc in rcs)
 
 
-def stage_flops(kind, cin, cout, h, w):
-    """Algorithmic FLOPs of one stage per tile (conv + fused GDN MACs x 2), input size h x w."""
+def stage_flops(kind, cin, cout, h, w, norm=False):
+    """Algorithmic FLOPs of one stage per tile, input size h x w: the convolution's MACs x 2 and, when the stage carries
+    a fused GDN / IGDN (norm), that layer's cout x cout MACs per output pixel x 2 - SURVEY.md 8(d) counts a tile's work
+    as "conv + GDN MACs x 2" (its 11.056 GFLOP per tile is 4823.4 M conv MACs + 704.6 M GDN MACs, both directions)."""
     if kind == "conv3":
-        return 2.0 * h * w * 9 * cin * cout
-    pix_out = (h // 2) * (w // 2) if kind == "conv" else (2 * h) * (2 * w)
-    taps = 25 if kind == "conv" else 25 / 4.0
-    return 2.0 * pix_out * taps * cin * cout
+        pix_out, taps = h * w, 9
+    else:
+        pix_out = (h // 2) * (w // 2) if kind == "conv" else (2 * h) * (2 * w)
+        taps = 25 if kind == "conv" else 25 / 4.0
+    return 2.0 * pix_out * (taps * cin * cout + (cout * cout if norm else 0))
 
 
 def quality_match(net, sd, x8):
@@ -338,13 +341,14 @@ def main():
         for key, evs in events.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
             per_stage_ms[key] = ms
-            fl = stage_flops(*key[:5]) * key[5]
-            stages["%s_%d_%d_%dx%d_b%d" % key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
+            fl = stage_flops(*key[:5], norm=key[6]) * key[5]
+            stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
 
         def roofline_of(key, kernel_name, traffic_file):
             LB = key[5]
             ms = per_stage_ms[key]
-            fl = stage_flops(*key[:5]) * LB
+            fl = stage_flops(*key[:5], norm=key[6]) * LB
+            fl_conv = stage_flops(*key[:5]) * LB
             ach = fl / (ms * 1e-3) / 1e12
             traffic = None
             tfile = os.path.join(ROOT, "profiles", traffic_file)
@@ -357,6 +361,9 @@ def main():
                                       "to this launch size)" % traffic_file,
                     "avg_launch_ms": round(ms, 4), "launches": len(events[key]), "tiles_per_launch": LB,
                     "algorithmic_flop_per_launch": fl,
+                    "algorithmic_flop_note": "convolution MACs x 2 + the fused GDN / IGDN's 128 x 128 MACs per output pixel x 2 "
+                                             "(SURVEY.md 8(d): a tile's work is conv + GDN MACs x 2)",
+                    "frac_conv_only": round(fl_conv / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                     "algorithmic_bytes_per_launch": 2 * (key[1] * key[3] * key[4] + key[2] * (key[3] * key[4] * (4 if key[0] == "deconv" else 0.25))) * LB}
 
         # `roofline` = the DOMINANT kernel of the step (largest total time among the MFMA stages, full-size launches);

@@ -262,38 +262,51 @@ constexpr int RING = 64, RING_LOW = 24, SYM_BUF = 16, LUT_BITS = 10;
 struct RingSource {
   const uint32_t *p;
   uint32_t *ring;  // LDS: word (i & (RING-1)) of this lane at ring[(i & (RING-1)) * 64]
-  int nw, rd, filled;
+  int nw, rd, filled, last;
   bool over;
-  __device__ inline uint32_t load_guarded(int i) const { return (i < nw) ? p[i] : 0u; }
-  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring) {
-    p = ptr; nw = n; ring = lane_ring; rd = 0; over = false; filled = 0;
+  // `fallback`: any readable device word, addressed instead of the stream when the stream is empty
+  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
+    p = n > 0 ? ptr : fallback; nw = n; last = n > 0 ? n - 1 : 0; ring = lane_ring; rd = 0; over = false; filled = 0;
     top_up();
     top_up();
   }
-  // up to 16 more words for every lane that has room (uniform control flow, per-lane predication)
+  // up to 16 more words for every lane that has room (uniform control flow, per-lane predication).  The loads are
+  // issued as asm with their own wait: loads the compiler knows about make it put a conservative s_waitcnt vmcnt(0)
+  // into every iteration of the symbol loop (the refill is a rarely taken branch of it), and that wait also waits
+  // for the symbol stores of the last flush - a memory round trip per SYM_BUF symbols on the serial chain.
   __device__ inline void top_up() {
     uint32_t w[16];
     const bool room = filled - rd <= RING - 16;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = room ? load_guarded(filled + j) : 0u;
+    for (int j = 0; j < 16; ++j) {
+      const int i = filled + j;
+      const uint32_t *a = p + (i < last ? i : last);  // past the end: re-read the last word, zeroed below
+      asm volatile("global_load_dword %0, %1, off" : "=v"(w[j]) : "v"(a));
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
+                   "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
     if (room) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ring[((filled + j) & (RING - 1)) * 64] = w[j];
+      for (int j = 0; j < 16; ++j) ring[((filled + j) & (RING - 1)) * 64] = (filled + j < nw) ? w[j] : 0u;
       filled += 16;
     }
   }
   __device__ inline void refill_if_low() {
     if (__any(filled - rd <= RING_LOW)) top_up();
   }
-  // branch-free pair for the common renormalisation: peek() the next word early, advance(true) if it was used
-  __device__ inline uint32_t peek() const { return (rd < filled && rd < nw) ? ring[(rd & (RING - 1)) * 64] : 0u; }
+  // branch-free pair for the common renormalisation: peek() the next word early, advance(true) if it was used.
+  // The ring read carries no guard (a guarded read becomes a branch with its own s_waitcnt, which serialises this LDS
+  // round trip with the table lookup's): words past the end of the stream are stored as zeros by top_up(), and the ring
+  // checks keep rd < filled (a block of SYM_BUF symbols consumes at most SYM_BUF <= RING_LOW words between checks).
+  __device__ inline uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
   __device__ inline void advance(bool used) {
     over = over || (used && rd >= nw);
     rd += used ? 1 : 0;
   }
   __device__ inline uint32_t next() {
     if (rd >= nw) over = true;
-    const uint32_t w = (rd < filled) ? ring[(rd & (RING - 1)) * 64] : 0u;  // rd >= filled only on malformed streams
+    const uint32_t w = ring[(rd & (RING - 1)) * 64];
     ++rd;
     return w;
   }
@@ -316,28 +329,31 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [RING][64] stream-word rings
   int32_t *s_out = reinterpret_cast<int32_t *>(s_ring + RING * 64);           // [SYM_BUF][64] decoded symbols
-  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(s_out + SYM_BUF * 64);       // [cdf_stride]
-  uint8_t *s_lut = reinterpret_cast<uint8_t *>(s_cdf) + (size_t)cdf_stride * 4;  // [1 << LUT_BITS] (uint16 when rows > 256 entries)
-  uint16_t *s_lut16 = reinterpret_cast<uint16_t *>(s_lut);
-  const bool wide = cdf_stride > 256;
+  uint2 *s_lut = reinterpret_cast<uint2 *>(s_out + SYM_BUF * 64);             // [1 << LUT_BITS] packed search records
+  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(s_lut + (1 << LUT_BITS));    // [cdf_stride]
   const int lane = threadIdx.x;
   const int b_raw = blockIdx.x * 64 + lane;
   const bool live = b_raw < B;
   const int b = live ? b_raw : B - 1;
   RingSource src;
-  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane);
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane,
+           reinterpret_cast<const uint32_t *>(byte_off));
   uint64_t x = (uint64_t)src.next();
   x |= (uint64_t)src.next() << 32;
   int32_t *sp = symbols + (size_t)b * ssb;
   for (int c = 0; c < C; ++c) {
-    const int len = cdf_len[c];
+    const int len = cdf_len[c] < 2 ? 2 : cdf_len[c];
     const int32_t max_value = len - 2;
     const int32_t off = offset[c];
     __syncthreads();
     for (int e = lane; e < len; e += 64) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
     __syncthreads();
-    // LUT over the top LUT_BITS bits of cf: largest s with cdf[s] <= k << (16 - LUT_BITS).  Each lane fills a run of
-    // consecutive keys: one binary search, then a forward walk.
+    // One record per value of the top LUT_BITS bits of cf, holding everything the common case needs so that the
+    // x -> x chain of a symbol carries ONE LDS round trip: with s = the largest symbol whose cdf[s] <= the bucket's
+    // first value, the record is { cdf[s], cdf[s+1] - 1, cdf[s+2] - 1, s } (16 bits each; "- 1" keeps 65536 in range).
+    // A bucket of 64 values that starts in symbol s reaches at most into s+1 unless a whole symbol of frequency < 64
+    // lies inside it; that case (the far tails) is detected by cf > cdf[s+2] - 1 and walks the table.
+    // Each lane fills a run of consecutive keys: one binary search, then a forward walk.
     constexpr int KPL = (1 << LUT_BITS) / 64;
     {
       const uint32_t key0 = (uint32_t)(lane * KPL) << (16 - LUT_BITS);
@@ -349,50 +365,65 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
       for (int k = 0; k < KPL; ++k) {
         const uint32_t key = (uint32_t)(lane * KPL + k) << (16 - LUT_BITS);
         while (lo + 1 < len - 1 && s_cdf[lo + 1] <= key) ++lo;
-        if (wide) s_lut16[lane * KPL + k] = (uint16_t)lo; else s_lut[lane * KPL + k] = (uint8_t)lo;
+        const uint32_t c0 = s_cdf[lo], c1 = s_cdf[lo + 1], c2 = s_cdf[lo + 2 < len ? lo + 2 : len - 1];
+        s_lut[lane * KPL + k] = make_uint2((c0 & 0xFFFFu) | ((c1 - 1u) << 16), ((c2 - 1u) & 0xFFFFu) | ((uint32_t)lo << 16));
       }
     }
     __syncthreads();
     if (!live) continue;  // idle lanes (last block only) sit out the decoding loop
-    for (int p = 0; p < plane; ++p) {
-      if ((p & 7) == 0) src.refill_if_low();  // a symbol takes at most one word off the ring outside the (rare) bypass path
-      // the next stream word is read before it is known to be needed: the LDS latency stays off the x -> x chain
-      const uint32_t w_next = src.peek();
-      const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-      int s = wide ? (int)s_lut16[cf >> (16 - LUT_BITS)] : (int)s_lut[cf >> (16 - LUT_BITS)];
-      uint32_t lo = s_cdf[s], hi = s_cdf[s + 1];
-      while (__any(hi <= cf)) {  // uniform loop, per-lane select: the fine LUT makes a second pass rare
-        const bool adv = hi <= cf;
-        const uint32_t nxt = s_cdf[s + 1 + (adv ? 1 : 0)];
-        lo = adv ? hi : lo;
-        s += adv ? 1 : 0;
-        hi = adv ? nxt : hi;
-      }
-      x = (uint64_t)(hi - lo) * (x >> 16) + cf - lo;
-      const bool need = x < RANS_L;
-      x = need ? ((x << 32) | w_next) : x;
-      src.advance(need);
-      int32_t value = s;
-      if (__any(value == max_value)) {  // uniform and rare: some stream hit the escape symbol
-        if (value == max_value) {
-          uint32_t val = get_bits4p(x, src);
-          int nb = (int)val;
-          while (val == 15u && nb < 64) { val = get_bits4p(x, src); nb += (int)val; }
-          uint32_t raw = 0;
-          for (int j = 0; j < nb; ++j) {
-            const uint32_t nib = get_bits4p(x, src);
-            if (j < 8) raw |= nib << (j * 4);
+    // blocks of SYM_BUF symbols: ring check | SYM_BUF symbols with no global-memory operation | flush.  A symbol takes at
+    // most one word off the ring outside the (rare) bypass path, and RING_LOW >= SYM_BUF.
+    static_assert(RING_LOW >= SYM_BUF, "a block may consume SYM_BUF words before the next ring check");
+    for (int p0 = 0; p0 < plane; p0 += SYM_BUF) {
+      src.refill_if_low();
+      const int nb = plane - p0 < SYM_BUF ? plane - p0 : SYM_BUF;
+      for (int k = 0; k < nb; ++k) {
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+        const uint2 rec = s_lut[cf >> (16 - LUT_BITS)];
+        // the next stream word is read before it is known to be needed: its LDS latency runs beside the lookup's
+        const uint32_t w_next = src.peek();
+        const uint32_t c1m = rec.x >> 16, c2m = rec.y & 0xFFFFu;
+        const bool adv = cf > c1m;
+        uint32_t lo = adv ? c1m + 1u : (rec.x & 0xFFFFu);
+        uint32_t him = adv ? c2m : c1m;  // cdf[s + 1] - 1 of the symbol taken
+        int s = (int)(rec.y >> 16) + (adv ? 1 : 0);
+        if (__any(cf > c2m)) {  // uniform, per-lane walk: some stream sits in a bucket that holds three or more symbols
+          if (cf > c2m) {
+            s = (int)(rec.y >> 16) + 2;
+            if (s > len - 2) s = len - 2;  // (malformed tables only)
+            lo = s_cdf[s];
+            uint32_t hi = s_cdf[s + 1];
+            while (s < len - 2 && hi <= cf) {
+              ++s;
+              lo = hi;
+              hi = s_cdf[s + 1];
+            }
+            him = hi - 1u;
           }
-          value = (int32_t)(raw >> 1);
-          value = (raw & 1u) ? -value - 1 : value + max_value;
         }
-        src.refill_if_low();  // the escape path may have drained several words
+        x = (uint64_t)(him + 1u - lo) * (x >> 16) + cf - lo;
+        const bool need = x < RANS_L;
+        x = need ? ((x << 32) | w_next) : x;
+        src.advance(need);
+        int32_t value = s;
+        if (__any(value == max_value)) {  // uniform and rare: some stream hit the escape symbol
+          if (value == max_value) {
+            uint32_t val = get_bits4p(x, src);
+            int nbyp = (int)val;
+            while (val == 15u && nbyp < 64) { val = get_bits4p(x, src); nbyp += (int)val; }
+            uint32_t raw = 0;
+            for (int j = 0; j < nbyp; ++j) {
+              const uint32_t nib = get_bits4p(x, src);
+              if (j < 8) raw |= nib << (j * 4);
+            }
+            value = (int32_t)(raw >> 1);
+            value = (raw & 1u) ? -value - 1 : value + max_value;
+          }
+          src.refill_if_low();  // the escape path may have drained several words
+        }
+        s_out[k * 64 + lane] = value + off;
       }
-      s_out[(p & (SYM_BUF - 1)) * 64 + lane] = value + off;
-      if ((p & (SYM_BUF - 1)) == SYM_BUF - 1 || p == plane - 1) {  // uniform: flush the buffered symbols
-        const int p0 = p & ~(SYM_BUF - 1);
-        for (int k = 0; k <= p - p0; ++k) sp[(size_t)((size_t)c * plane + p0 + k) * ssi] = s_out[k * 64 + lane];
-      }
+      for (int k = 0; k < nb; ++k) sp[(size_t)((size_t)c * plane + p0 + k) * ssi] = s_out[k * 64 + lane];
     }
   }
   if (live && src.over) atomicOr(status, 1);
@@ -560,7 +591,8 @@ __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *
     __syncthreads();
   }
   RingSource src;
-  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane);
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane,
+           reinterpret_cast<const uint32_t *>(byte_off));
   uint64_t x = (uint64_t)src.next();
   x |= (uint64_t)src.next() << 32;
   int32_t *sp = symbols + (size_t)b * ssb;
@@ -682,8 +714,8 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + (size_t)cdf_stride * 4 + ((size_t)2 << LUT_BITS);
-  if (!indexes && n % plane == 0 && dec_lds <= 64 * 1024) {
+  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
+  if (!indexes && n % plane == 0 && dec_lds <= 64 * 1024 && cdf_stride <= 65535) {
     hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);

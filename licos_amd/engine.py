@@ -21,7 +21,8 @@ from .layers import GDN, conv_geometry
 _cache = weakref.WeakKeyDictionary()
 
 # Optional per-stage device timing (bench.py): when set to a dict, every stage launch is bracketed by
-# HIP events recorded on the stream the kernel is launched on; key = (kind, Cin, Cout, H, W, tiles in the launch).
+# HIP events recorded on the stream the kernel is launched on; key = (kind, Cin, Cout, H, W, tiles in the launch,
+# stage carries a fused GDN / IGDN).
 stage_events = None
 
 
@@ -150,30 +151,31 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
             fewch = "scatter"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
         if fewch == "scatter":
-            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], False)
             cur = _timed(key, lambda: ops.deconv5x5s2_scatter_f16(cur, wp, bp, m.in_channels, m.out_channels,
                                                                   clamp01=clamp01, out=out, in_xsplit=xsplit))
             xsplit = False  # NCHW fp32 from here
             continue
         if fewch:
-            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], False)
             cur = _timed(key, lambda: ops.deconv5x5s2_fewch_f16(cur, wp, bp, m.in_channels, m.out_channels,
                                                                 clamp01=clamp01, out=out))
             continue
         gp = _packed_gdn(g) if isinstance(g, GDN) else None
         epi = ops.EPI_NONE if g is None else ops.EPI_RELU if g == "relu" else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
+        norm = gp is not None
         if s2d_first and idx == 0:
-            key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0])
+            key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0], norm)
             cur = _timed(key, lambda: ops.conv5x5s2_s2d_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, h0, w0,
                                                             out_nchw=last, out=out if last else None))
             continue
         if isinstance(m, nn.Conv2d) and not isinstance(m, nn.ConvTranspose2d) and conv_geometry(m)[:3] == (3, 1, 1):
-            key = ("conv3", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            key = ("conv3", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], norm)
             cur = _timed(key, lambda: ops.conv3x3s1_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))
         elif isinstance(m, nn.ConvTranspose2d):
             hh, ww = cur.shape[2], cur.shape[3]
-            key = ("deconv", m.in_channels, m.out_channels, hh, ww, cur.shape[0])
+            key = ("deconv", m.in_channels, m.out_channels, hh, ww, cur.shape[0], norm)
             # one output phase = every other pixel of a row: hand the next kernel the x-split layout when both sides
             # speak it (whole-line stores here, nothing lost there: LDS-DMA addresses are per lane anyway)
             flags = ops.EPI_IN_XSPLIT if xsplit else 0
@@ -186,7 +188,7 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
                                                           out=out if last else None))
             xsplit = out_split
         else:
-            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0])
+            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], norm)
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,
                                                         out_nchw=last, out=out if last else None))
     assert not xsplit, "a transform chain must not end in the x-split layout"

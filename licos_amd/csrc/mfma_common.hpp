@@ -137,19 +137,22 @@ struct MfmaArgs {
   int s1conv;             // deconv kernel used as a 3x3 stride-1 conv (space-to-depth first stage): one 'phase', no upsampling
   const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
   int in_xsplit, out_xsplit;  // LICOS_EPI_IN_XSPLIT / LICOS_EPI_OUT_XSPLIT (mfma_deconv8.hip only)
+  int w_mt_total, halves;     // mfma_conv8.hip pair mode: 32-channel tiles in the packed weights, channel groups per tile
 };
 
 // ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
 template <int MT, int NT, int EPI>
 __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, const bf16x8 *gamma, int b,
-                                      const int (&oy)[NT], const int (&ox)[NT], int lane) {
+                                      const int (&oy)[NT], const int (&ox)[NT], int lane, int c_base = 0) {
+  // b may differ per lane (two images side by side in one pixel tile); c_base: first output channel of this
+  // workgroup's channel group (a multiple of 32; epilogues without a norm only)
   const int h = lane >> 5;
   // bias: channel of register q in tile mt is 32mt + (q&3) + 8(q>>2) + 4h
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 bv = *reinterpret_cast<const float4 *>(a.bias + 32 * mt + 8 * g + 4 * h);
+      const float4 bv = *reinterpret_cast<const float4 *>(a.bias + c_base + 32 * mt + 8 * g + 4 * h);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         acc[mt][nt][4 * g + 0] += bv.x;
@@ -234,7 +237,7 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
             lo[d] = sw[0];
             hi[d] = sw[1];
           }
-          const int chunk = 2 * it + gp;
+          const int chunk = (c_base >> 4) + 2 * it + gp;
           if (live && chunk < Cout16) {
             _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + chunk) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + 8 * h;
             *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
@@ -243,7 +246,7 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int c0 = 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
+          const int c0 = c_base + 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[it][nt][4 * g + e];

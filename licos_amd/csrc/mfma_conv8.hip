@@ -31,7 +31,13 @@ struct Conv8Geom {
   static constexpr int ODD_PER_STEP = (ODD_Q + 2) / 3, EVEN_PER_STEP = (EVEN_Q + 1) / 2;
 };
 
-template <int MT, int EPI>
+// PAIR: maps whose output is 16 pixels wide (the last analysis stage, 32^2 -> 16^2 at 256^2 tiles).  Two images share a
+// pixel tile: lanes r < 16 of a row are image 2b, lanes r >= 16 image 2b + 1.  A parity plane row holds 36 granules per x
+// parity; one image needs 18 of them (input columns -2 .. 33), so the second image's patch sits at granule 18 and its
+// lanes read at r - 16 + 18 = r + 2.  Wide layers (Cout = 192: six 32-channel tiles, too many accumulators for two waves
+// per SIMD) run as a.halves channel groups of MT tiles each, one workgroup per group; the input patch of the second
+// group comes out of the XCD's L2.
+template <int MT, int EPI, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
   using G = Conv8Geom<MT>;
   constexpr int NT = G::NT;
@@ -42,19 +48,26 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  int b, tile;
-  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
-  const int oy0 = (tile / a.tiles_x) * G::TH, ox0 = (tile % a.tiles_x) * G::TW;
+  int b, tile, mt0 = 0;
+  if (PAIR) {
+    xcd_work_item(blockIdx.x, (a.B + 1) >> 1, a.tiles_y * a.halves, b, tile);
+    mt0 = (tile % a.halves) * MT;
+    tile /= a.halves;
+  } else {
+    xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  }
+  const int oy0 = PAIR ? tile * G::TH : (tile / a.tiles_x) * G::TH, ox0 = PAIR ? 0 : (tile % a.tiles_x) * G::TW;
   const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
+  const int img = PAIR ? (r >> 4) : 0;  // which image of the pair this lane's pixel belongs to
 
   int base_e[NT], base_o[NT], oy[NT], ox[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int ty = wave * NT + nt;
-    oy[nt] = oy0 + ty;
-    ox[nt] = ox0 + r;
-    base_e[nt] = h * (G::NR_E * G::ROWG) + ty * G::ROWG + r;
-    base_o[nt] = h * (G::NR_O * G::ROWG) + ty * G::ROWG + r;
+    oy[nt] = (PAIR && 2 * b + img >= a.B) ? -1 : oy0 + ty;  // (an odd batch: the last pair's second image does not exist)
+    ox[nt] = PAIR ? (r & 15) : ox0 + r;
+    base_e[nt] = h * (G::NR_E * G::ROWG) + ty * G::ROWG + r + 2 * img;
+    base_o[nt] = h * (G::NR_O * G::ROWG) + ty * G::ROWG + r + 2 * img;
   }
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
       for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
 
   const size_t plane = (size_t)a.H * a.W;
-  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)(PAIR ? 2 * b : b) * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
   // per-lane source offset (half8 units inside a chunk plane) of this wave's patch pieces; -1 = outside the image
@@ -75,10 +88,15 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
     if (d >= limit) return -1;
     const int hh = d / (nrows * G::ROWG), rem = d - hh * (nrows * G::ROWG);
     const int j = rem / G::ROWG, r2 = rem - j * G::ROWG;
-    const int par = r2 / G::PWH, xh = r2 - par * G::PWH;
+    const int par = r2 / G::PWH;
+    int xh = r2 - par * G::PWH, second = 0;
+    if (PAIR && xh >= G::PWH / 2) {
+      xh -= G::PWH / 2;
+      second = 1;
+    }
     const int iy = iy0 + 2 * j + row_parity, ix = ix0 + 2 * xh + par;
-    if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) return -1;
-    return (iy * a.W + ix) * 2 + hh;
+    if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W || (second && 2 * b + 1 >= a.B)) return -1;
+    return second * (int)(a.Cin16 * plane * 2) + (iy * a.W + ix) * 2 + hh;
   };
 #pragma unroll
   for (int i = 0; i < G::NPE; ++i) e_off[i] = piece_offset(wave + 8 * i, G::NR_E, 0, G::EVEN_GRAN);
@@ -103,11 +121,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
     }
   };
   auto dma_w = [&](int cc, int ky, int buf) {
-    const half8 *wsrc = a.wp + (size_t)(cc * 5 + ky) * G::W_GRAN + lane;
+    // one kernel row of a cin chunk = [kx][32-channel tile][64 lanes]; a channel group takes MT of the w_mt_total tiles
+    const int mtt = PAIR ? a.w_mt_total : MT;
+    const half8 *wsrc = a.wp + (size_t)(cc * 5 + ky) * (5 * mtt * 64) + lane;
 #pragma unroll
     for (int i = 0; i < G::NPW; ++i) {
       const int q = wave + 8 * i;
-      if (q < G::W_Q) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN + q * 64);
+      if (q < G::W_Q) glds16(wsrc + (PAIR ? (q / MT) * mtt + mt0 + q % MT : q) * 64, s_wbuf + buf * G::W_GRAN + q * 64);
     }
   };
 
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
     __syncthreads();
     gam = s_gamma;
   }
-  epilogue_store<MT, NT, EPI>(acc, a, gam, b, oy, ox, lane);
+  epilogue_store<MT, NT, EPI>(acc, a, gam, PAIR ? 2 * b + img : b, oy, ox, lane, 32 * mt0);
 }
 
 template <int MT, int EPI>
@@ -193,8 +213,39 @@ static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
   return LICOS_OK;
 }
 
+template <int MT, int EPI>
+static int launch_conv8_pair(const MfmaArgs &a0, int mt_total, hipStream_t s) {
+  using G = Conv8Geom<MT>;
+  MfmaArgs a = a0;
+  a.tiles_x = 1;
+  a.tiles_y = a.Ho / G::TH;
+  a.w_mt_total = mt_total;
+  a.halves = mt_total / MT;
+  auto kern = conv5x5s2_mfma8_kernel<MT, EPI, true>;
+  const size_t lds = (size_t)G::TOTAL_GRAN * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long blocks = (long)((a.B + 1) / 2) * a.tiles_y * a.halves;
+  LICOS_REQUIRE(blocks < (1L << 31), "conv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 // returns LICOS_OK after launching, or 1 when this variant does not apply (caller falls back to the 4-wave kernel)
 int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
+  // 16-pixel-wide outputs, two images per pixel tile; 192 output channels as two groups of 96 (no norm across groups).
+  // Also for a batch of one (half the lanes idle): a tile's bytes must not depend on the batch it was coded in, and the
+  // 4-wave kernel adds its partial sums in a different order.
+  if (a.Wo == 16 && a.W == 32 && a.Ho >= 16 && (a.Ho % 16) == 0 && !a.accum && (long)a.Cin16 * a.H * a.W * 2 < (1L << 30)) {
+    if (MT == 6 && epi == EPI_NONE) return launch_conv8_pair<3, EPI_NONE>(a, 6, s);
+    if (MT == 6 && epi == EPI_RELU) return launch_conv8_pair<3, EPI_RELU>(a, 6, s);
+    if (MT == 4 && epi == EPI_NONE) return launch_conv8_pair<4, EPI_NONE>(a, 4, s);
+    if (MT == 4 && epi == EPI_RELU) return launch_conv8_pair<4, EPI_RELU>(a, 4, s);
+  }
   if (MT != 4 || a.Ho < 16 || a.Wo < 32 || (a.Ho % 16) != 0) return 1;
   if (epi == EPI_GDN) return launch_conv8<4, EPI_GDN>(a, s);
   if (epi == EPI_NONE) return launch_conv8<4, EPI_NONE>(a, s);

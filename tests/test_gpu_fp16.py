@@ -67,6 +67,33 @@ def test_conv_stage_exact_operands(cin, cout, h, w):
     assert elementwise_close(ops.blk16_to_nchw_f32(outb, cout), ref, 4.9e-4, 2e-5)  # one fp16 rounding of the fp32 sum
 
 
+@pytest.mark.parametrize("batch,cin,cout,h,w,relu", [(3, 128, 192, 32, 32, False), (5, 128, 192, 32, 32, True), (2, 128, 128, 64, 32, False),
+                                                     (7, 192, 128, 32, 32, True), (4, 128, 192, 96, 32, False), (2, 16, 192, 32, 32, False)])
+def test_conv_two_images_per_pixel_tile(batch, cin, cout, h, w, relu):
+    """16-pixel-wide outputs (the last analysis stage of a 256^2 tile): the 8-wave kernel puts two images side by side
+    in one 16 x 32 pixel tile and runs 192 channels as two groups of 96.  Odd batches (a pair with one image), several
+    tile rows, both channel-group counts, the ReLU epilogue; against torch conv2d on the same fp16-exact operands."""
+    g = torch.Generator().manual_seed(batch * 1000 + cin + cout + h)
+    x = h16(torch.randn(batch, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 5, 5, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride=2, padding=2)
+    if relu:
+        ref = ref.relu()
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    epi = ops.EPI_RELU if relu else ops.EPI_NONE
+    out = ops.conv5x5s2_f16(xb, wp, bp, None, epi, cin, cout, out_nchw=True)
+    assert out.shape == ref.shape
+    assert elementwise_close(out, ref, 1e-5, 2e-5)
+    outb = ops.conv5x5s2_f16(xb, wp, bp, None, epi, cin, cout, out_nchw=False)
+    assert elementwise_close(ops.blk16_to_nchw_f32(outb, cout), ref, 4.9e-4, 2e-5)
+    # the result must not depend on which images share a tile: the last image alone in a batch of one, bit for bit
+    one = ops.conv5x5s2_f16(ops.nchw_f32_to_blk16(x[batch - 1:].to(DEV)), wp, bp, None, epi, cin, cout, out_nchw=True)
+    assert torch.equal(one, out[batch - 1:])
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
                                            (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19),
                                            (128, 7, 9, 40), (192, 24, 8, 33),

@@ -13,13 +13,17 @@
 //   * the (I)GDN epilogue squares and converts each accumulator ONCE per pixel tile (the 4-wave kernel's shared
 //     epilogue redoes it for every 32-channel output tile).
 // 146 KB of LDS, one workgroup (2 waves per SIMD) per CU.
+//
+// PAIR: maps that are 16 pixels wide (the first synthesis stage of a 256^2 tile, 16^2 -> 32^2).  Two images share a pixel
+// tile: lanes r < 16 of a row are image 2b, lanes r >= 16 image 2b + 1; a patch row (36 granules) holds the 18 columns
+// -1 .. 16 of each image, so the second image's lanes read at r - 16 + 18 = r + 2.
 #include <cstdlib>
 
 #include "mfma_deconv8.hpp"
 
 namespace licos {
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   using G = Deconv8Geom<MT>;
   constexpr int NT = G::NT;
@@ -35,12 +39,13 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   int b, tile;
-  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  xcd_work_item(blockIdx.x, PAIR ? (a.B + 1) >> 1 : a.B, a.tiles_x * a.tiles_y, b, tile);
   const int nphase = a.s1conv ? 1 : 4;
   const int ty0 = (tile / a.tiles_x) * G::TH, tx0 = (tile % a.tiles_x) * G::TW;
+  const int img = PAIR ? (r >> 4) : 0;  // which image of the pair this lane's pixel belongs to
 
   const size_t plane = (size_t)a.H * a.W;
-  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)(PAIR ? 2 * b : b) * a.Cin16 * plane * 2;
   const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
 
   // per-lane source offset of this wave's patch pieces inside a chunk plane (-1: outside the image / padding); the
@@ -50,11 +55,16 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   for (int i = 0; i < G::NPP; ++i) {
     const int d = (wave + 8 * i) * 64 + lane;
     const int hh = d / G::HALF, rem = d - hh * G::HALF;
-    const int j = rem / G::RS, q = rem - j * G::RS;
+    const int j = rem / G::RS;
+    int q = rem - j * G::RS, second = 0;
+    if (PAIR && q >= G::RS / 2) {
+      q -= G::RS / 2;
+      second = 1;
+    }
     const int iy = ty0 - 1 + j, ix = tx0 - 1 + q;
-    const bool ok = d < G::PATCH_GRAN && q < G::TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const bool ok = d < G::PATCH_GRAN && (PAIR || q < G::TW + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && 2 * b + second < (PAIR ? a.B : 2 * a.B);
     const int pix = a.in_xsplit ? (iy * 2 + (ix & 1)) * (a.W >> 1) + (ix >> 1) : iy * a.W + ix;
-    p_off[i] = ok ? pix * 2 + hh : -1;
+    p_off[i] = ok ? second * (int)(a.Cin16 * plane * 2) + pix * 2 + hh : -1;
   }
   auto dma_patch = [&](int cc, int buf) {
     const half8 *xin = xb + (size_t)cc * plane * 2;
@@ -103,12 +113,12 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   bool all_live = a.Cout >= 32 * MT - 15;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int ty = wave * NT + nt, tx = r;
-    const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W;
+    const int ty = wave * NT + nt, tx = PAIR ? (r & 15) : r;
+    const bool in = (ty0 + ty) < a.H && (tx0 + tx) < a.W && (!PAIR || 2 * b + img < a.B);
     oyh[nt] = in ? ty0 + ty : -1;
     oxh[nt] = tx0 + tx;
     all_live = all_live && (ty0 + ty) < a.H;  // wave-uniform: a live row issues its stores whatever its columns
-    base[nt] = h * G::HALF + (ty + 1) * G::RS + (tx + 1);  // patch row 0 / column 0 = input row ty0-1 / column tx0-1
+    base[nt] = h * G::HALF + (ty + 1) * G::RS + (r + 1) + 2 * img;  // patch row 0 / column 0 = input row ty0-1 / column tx0-1
   }
   // accumulators start at the bias: channel of register q in tile mt is 32mt + (q&3) + 8(q>>2) + 4h
   f32x16 acc[MT][NT];
@@ -181,9 +191,10 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
       const bool live = oyh[nt] >= 0 && oy < a.Ho && ox < a.Wo;
       // x-split output: row oy as [even-x pixels][odd-x pixels] - this phase's pixels of the row are one run
       pix[nt] = !live ? -1 : (a.out_xsplit ? ((long)oy * 2 + px) * a.W + oxh[nt] : (long)oy * a.Wo + ox);
+      if (PAIR && live) pix[nt] += (long)img * Cout16 * a.Ho * a.Wo;  // the second image's planes
     }
-    tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, a.y_blk + (size_t)b * Cout16 * a.Ho * a.Wo * 16, (size_t)a.Ho * a.Wo, Cout16,
-                                pix, lane);
+    tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, a.y_blk + (size_t)(PAIR ? 2 * b : b) * Cout16 * a.Ho * a.Wo * 16,
+                                (size_t)a.Ho * a.Wo, Cout16, pix, lane);
     if (phase + 1 < nphase) acc_init();
   };
   run_phase(I3{}, I3{}, std::integral_constant<int, 0>{});
@@ -194,20 +205,20 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   }
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool PAIR = false>
 static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
   using G = Deconv8Geom<MT>;
   MfmaArgs a = a0;
-  a.tiles_x = cdiv(a.W, G::TW);
+  a.tiles_x = PAIR ? 1 : cdiv(a.W, G::TW);
   a.tiles_y = cdiv(a.H, G::TH);
   const size_t lds = (size_t)16 * (G::KLOOP_GRAN + 16 * MT + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
-  auto kern = deconv5x5s2_mfma8_kernel<MT, EPI>;
+  auto kern = deconv5x5s2_mfma8_kernel<MT, EPI, PAIR>;
   static bool attr_set = false;
   if (!attr_set) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const long blocks = (long)a.tiles_x * a.tiles_y * a.B;  // a workgroup walks all four phases of its tile
+  const long blocks = (long)a.tiles_x * a.tiles_y * (PAIR ? (a.B + 1) / 2 : a.B);  // a workgroup walks all four phases of its tile
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
   LICOS_LAUNCH_CHECK();
@@ -217,11 +228,20 @@ static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
 // returns LICOS_OK after launching, or 1 when this variant does not apply (caller falls back to the 4-wave kernel)
 bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv) {
   static const bool enabled = [] { const char *e = getenv("LICOS_DECONV8"); return !(e && e[0] == '0'); }();
-  return enabled && MT == 4 && H >= 16 && W >= 32 && blk_out && !accum && (Cin16 >= 2 || s1conv);
+  // (W == 16: two images per pixel tile - also for a batch of one, so that a tile's result does not depend on the batch)
+  return enabled && MT == 4 && H >= 16 && (W >= 32 || (W == 16 && !s1conv)) && blk_out && !accum && (Cin16 >= 2 || s1conv);
 }
 
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
   if (!mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, a.y_blk != nullptr, a.accum != 0, a.s1conv != 0)) return 1;
+  if (a.W == 16) {
+    LICOS_REQUIRE((long)a.Cin16 * a.H * a.W * 2 < (1L << 30), "deconv5x5s2_f16: image too large");
+    if (epi == EPI_IGDN) return launch_deconv8<4, EPI_IGDN, true>(a, s);
+    if (epi == EPI_NONE) return launch_deconv8<4, EPI_NONE, true>(a, s);
+    if (epi == EPI_RELU) return launch_deconv8<4, EPI_RELU, true>(a, s);
+    if (epi == EPI_GDN) return launch_deconv8<4, EPI_GDN, true>(a, s);
+    return 1;
+  }
   if (epi == EPI_IGDN) return launch_deconv8<4, EPI_IGDN>(a, s);
   if (epi == EPI_GDN) return launch_deconv8<4, EPI_GDN>(a, s);
   if (epi == EPI_NONE) return launch_deconv8<4, EPI_NONE>(a, s);

@@ -129,8 +129,46 @@ def test_deconv_stage_exact_operands(cin, cout, h, w):
         assert rel_err(outf, ref.clamp(0, 1)) < 2e-5
 
 
+@pytest.mark.parametrize("batch,cin,cout,h,w,igdn", [(3, 192, 128, 16, 16, True), (5, 192, 128, 16, 16, False), (2, 128, 128, 33, 16, True),
+                                                     (1, 192, 128, 16, 16, True), (4, 128, 96, 16, 16, False)])
+def test_deconv_two_images_per_pixel_tile(batch, cin, cout, h, w, igdn):
+    """16-pixel-wide inputs (the first synthesis stage of a 256^2 tile): the 8-wave transposed conv puts two images side
+    by side in one 16 x 32 pixel tile.  Odd batches, ragged tile rows, with and without the fused IGDN; against torch
+    conv_transpose2d (+ the oracle's IGDN arithmetic) on fp16-exact operands, and bit for bit against the same image
+    coded alone."""
+    from licos_amd import engine
+    from licos_amd.layers import GDN
+    g = torch.Generator().manual_seed(batch * 100 + cin + h)
+    x = h16(torch.randn(batch, cin, h, w, generator=g))
+    wt = h16(torch.randn(cin, cout, 5, 5, generator=g) * 0.04)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    gp, e = None, ops.EPI_NONE
+    if igdn:
+        m = GDN(cout, inverse=True).to(DEV)
+        with torch.no_grad():
+            m.gamma.add_((0.02 * torch.rand(cout, cout, generator=g)).to(DEV))
+            beta, gamma = m.effective()
+        gp, e = engine._packed_gdn(m), ops.EPI_IGDN
+        norm = F.conv2d(ref * ref, gamma.cpu().reshape(cout, cout, 1, 1), beta.cpu())
+        ref = ref * torch.sqrt(norm)
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV), transposed=True)
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    assert ops.deconv_layouts(cin, h, w, cout) == (ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT)
+    out = ops.deconv5x5s2_f16(xb, wp, bp, gp, e, cin, cout)
+    got = ops.blk16_to_nchw_f32(out, cout).cpu()
+    assert got.shape == ref.shape
+    tol = 4e-3 if igdn else 4.9e-4  # the fused norm runs on bf16 squares (test_fused_gdn_stage's bound)
+    assert bool(((got - ref).abs() <= tol * ref.abs() + (2e-3 if igdn else 2e-5) * float(ref.abs().max())).all())
+    one = ops.deconv5x5s2_f16(ops.nchw_f32_to_blk16(x[batch - 1:].to(DEV)), wp, bp, gp, e, cin, cout)
+    assert torch.equal(one, out[batch - 1:])
+
+
 @pytest.mark.parametrize("cin,cout,h,w,epi", [(128, 128, 32, 32, "igdn"), (128, 128, 40, 80, "none"), (192, 96, 18, 34, "relu"),
-                                               (128, 128, 64, 64, "igdn")])
+                                               (128, 128, 64, 64, "igdn"),
+                                               # 16-pixel-wide maps: two images per pixel tile
+                                               (192, 128, 16, 16, "igdn"), (128, 128, 40, 16, "relu")])
 def test_deconv_xsplit_layouts_are_bit_exact(cin, cout, h, w, epi):
     """The x-split activation layout (rows as [even-x pixels][odd-x pixels], LICOS_EPI_IN/OUT_XSPLIT) is a pure
     re-ordering: every combination of input / output layout gives bit for bit the values of the plain blk16 call, in
@@ -170,8 +208,8 @@ def test_deconv_xsplit_layouts_are_bit_exact(cin, cout, h, w, epi):
         assert torch.equal(ops.deconv5x5s2_scatter_f16(xs, ws, b3, cin, 3, in_xsplit=True),
                            ops.deconv5x5s2_scatter_f16(xb, ws, b3, cin, 3))
     # stages that have no x-split form say so, and the flags are refused there
-    assert ops.deconv_layouts(192, 16, 16, 128) == 0 and ops.deconv_layouts(128, 64, 64, 192) == 0
-    small = torch.zeros(1, 12, 16, 16, 16, device=DEV, dtype=torch.float16)
+    assert ops.deconv_layouts(192, 8, 8, 128) == 0 and ops.deconv_layouts(128, 64, 64, 192) == 0 and ops.deconv_layouts(192, 16, 24, 128) == 0
+    small = torch.zeros(1, 12, 8, 8, 16, device=DEV, dtype=torch.float16)
     with pytest.raises(ValueError):
         ops.deconv5x5s2_f16(small, ops.pack_conv_w_f16(torch.zeros(192, 128, 5, 5, device=DEV), transposed=True),
                             ops.pad_bias(torch.zeros(128, device=DEV), 128, DEV), None, ops.EPI_NONE | ops.EPI_OUT_XSPLIT, 192, 128)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const uint8_t *__restri
 // the decoder keeps the next two stream words in registers so renormalisation never waits on HBM.
 constexpr int SYM_BATCH = 8;
 
-__global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__restrict__ symbols, long ssb, long ssi,
+__global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *__restrict__ symbols, long ssb, long ssi,
                                                                int C, int plane, int cdf_stride,
                                                                const int32_t *__restrict__ cdf_len,
                                                                const int32_t *__restrict__ offset,
@@ -175,8 +175,9 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
                                                                int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   EncRec *s_tab = reinterpret_cast<EncRec *>(smem_raw);
-  const int lane = threadIdx.x;
-  const int b_raw = blockIdx.x * 64 + lane;
+  // a workgroup is blockDim.x / 64 independent waves that share the staged table (see coder_waves() below)
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int b_raw = (blockIdx.x * (nthr >> 6) + (tid >> 6)) * 64 + lane;
   const bool live = b_raw < B;
   const int b = live ? b_raw : B - 1;  // idle lanes shadow the last stream (no stores)
   WordSink sink{words, B, b, cap_words, false};
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64) void rans_encode_plane_kernel(const int32_t *__
     const int32_t max_value = len - 2;
     const int32_t off = offset[c];
     __syncthreads();
-    for (int e = lane; e < len - 1; e += 64) s_tab[e] = table[(size_t)c * cdf_stride + e];
+    for (int e = tid; e < len - 1; e += nthr) s_tab[e] = table[(size_t)c * cdf_stride + e];
     __syncthreads();
     if (!live) continue;  // idle lanes (last block only) sit out the coding loop: no per-symbol predication for them
     // symbols are fetched one batch ahead, so their load latency hides under the coding of the current batch
@@ -319,7 +320,7 @@ __device__ inline uint32_t get_bits4p(uint64_t &x, RingSource &src) {
   return val;
 }
 
-__global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(256) void rans_decode_plane_kernel(const uint8_t *__restrict__ in,
                                                                const int64_t *__restrict__ byte_off, long ssb, long ssi,
                                                                int C, int plane, const int32_t *__restrict__ cdf,
                                                                int cdf_stride, const int32_t *__restrict__ cdf_len,
@@ -327,12 +328,13 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
                                                                int32_t *__restrict__ symbols, int32_t *__restrict__ status,
                                                                int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw);                  // [RING][64] stream-word rings
-  int32_t *s_out = reinterpret_cast<int32_t *>(s_ring + RING * 64);           // [SYM_BUF][64] decoded symbols
-  uint2 *s_lut = reinterpret_cast<uint2 *>(s_out + SYM_BUF * 64);             // [1 << LUT_BITS] packed search records
+  // a workgroup is blockDim.x / 64 independent waves (own ring and symbol buffer) that share the channel's tables
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw) + wave * (RING * 64);            // [waves][RING][64] stream-word rings
+  int32_t *s_out = reinterpret_cast<int32_t *>(smem_raw) + nwave * (RING * 64) + wave * (SYM_BUF * 64);  // [waves][SYM_BUF][64]
+  uint2 *s_lut = reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(smem_raw) + nwave * (RING + SYM_BUF) * 64);  // [1 << LUT_BITS]
   uint32_t *s_cdf = reinterpret_cast<uint32_t *>(s_lut + (1 << LUT_BITS));    // [cdf_stride]
-  const int lane = threadIdx.x;
-  const int b_raw = blockIdx.x * 64 + lane;
+  const int b_raw = (blockIdx.x * nwave + wave) * 64 + lane;
   const bool live = b_raw < B;
   const int b = live ? b_raw : B - 1;
   RingSource src;
@@ -346,27 +348,27 @@ __global__ __launch_bounds__(64) void rans_decode_plane_kernel(const uint8_t *__
     const int32_t max_value = len - 2;
     const int32_t off = offset[c];
     __syncthreads();
-    for (int e = lane; e < len; e += 64) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
+    for (int e = tid; e < len; e += nthr) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
     __syncthreads();
     // One record per value of the top LUT_BITS bits of cf, holding everything the common case needs so that the
     // x -> x chain of a symbol carries ONE LDS round trip: with s = the largest symbol whose cdf[s] <= the bucket's
     // first value, the record is { cdf[s], cdf[s+1] - 1, cdf[s+2] - 1, s } (16 bits each; "- 1" keeps 65536 in range).
     // A bucket of 64 values that starts in symbol s reaches at most into s+1 unless a whole symbol of frequency < 64
     // lies inside it; that case (the far tails) is detected by cf > cdf[s+2] - 1 and walks the table.
-    // Each lane fills a run of consecutive keys: one binary search, then a forward walk.
-    constexpr int KPL = (1 << LUT_BITS) / 64;
+    // Each thread fills a run of consecutive keys: one binary search, then a forward walk.
+    const int KPL = (1 << LUT_BITS) / nthr;
     {
-      const uint32_t key0 = (uint32_t)(lane * KPL) << (16 - LUT_BITS);
+      const uint32_t key0 = (uint32_t)(tid * KPL) << (16 - LUT_BITS);
       int lo = 0, hi = len - 1;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (s_cdf[mid] <= key0) lo = mid; else hi = mid;
       }
       for (int k = 0; k < KPL; ++k) {
-        const uint32_t key = (uint32_t)(lane * KPL + k) << (16 - LUT_BITS);
+        const uint32_t key = (uint32_t)(tid * KPL + k) << (16 - LUT_BITS);
         while (lo + 1 < len - 1 && s_cdf[lo + 1] <= key) ++lo;
         const uint32_t c0 = s_cdf[lo], c1 = s_cdf[lo + 1], c2 = s_cdf[lo + 2 < len ? lo + 2 : len - 1];
-        s_lut[lane * KPL + k] = make_uint2((c0 & 0xFFFFu) | ((c1 - 1u) << 16), ((c2 - 1u) & 0xFFFFu) | ((uint32_t)lo << 16));
+        s_lut[tid * KPL + k] = make_uint2((c0 & 0xFFFFu) | ((c1 - 1u) << 16), ((c2 - 1u) & 0xFFFFu) | ((uint32_t)lo << 16));
       }
     }
     __syncthreads();
@@ -669,6 +671,21 @@ __global__ __launch_bounds__(64) void rans_decode_indexed_kernel(const uint8_t *
 
 using namespace licos;
 
+// Waves per workgroup of the plane coders.  A coder wave is a latency chain that leaves its CU almost idle - but a CU
+// that holds one cannot take a workgroup of the 8-wave transform kernels, which need every register of all four SIMDs
+// (2 waves x 256 VGPRs each), and the coders run BESIDE the transforms of the neighbouring chunk.  One wave per
+// workgroup spreads 4096 streams over 64 CUs (a quarter of the chip closed to the transforms for the 10-20 ms a coder
+// launch lasts); two waves per workgroup close 32, four - one per SIMD, so no wave shares an issue port - 16.  Measured
+// on the bench step: 1 wave 230.7 ms, 2 waves 227.6 ms, 4 waves 228.4 ms (the waves of a workgroup wait for each other
+// at every channel's table: a 4-wave encode launch takes 8.7 instead of 7.9 ms, and the last one of a step is exposed).
+// LICOS_CODER_WAVES (1, 2 or 4) overrides for A/B runs.
+static int coder_waves(int B) {
+  static const int forced = [] { const char *e = getenv("LICOS_CODER_WAVES"); return e ? atoi(e) : 0; }();
+  int w = (forced == 1 || forced == 2 || forced == 4) ? forced : 2;
+  while (w > 1 && B <= 64 * (w / 2)) w /= 2;  // small batches: no more waves than there are streams for
+  return w;
+}
+
 extern "C" {
 
 int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long ssb, long ssi, int n, int plane,
@@ -680,7 +697,8 @@ int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long
   LICOS_REQUIRE(B > 0 && n > 0 && cap_words >= 2 && cdf_stride > 1, "rans_encode_batch: bad sizes B=%d n=%d cap=%d", B, n, cap_words);
   LICOS_REQUIRE(indexes || plane > 0, "rans_encode_batch: need indexes or a plane size");
   if (!indexes && n % plane == 0 && (size_t)cdf_stride * sizeof(EncRec) <= 64 * 1024) {
-    hipLaunchKernelGGL(rans_encode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)cdf_stride * sizeof(EncRec),
+    const int cw = coder_waves(B);
+    hipLaunchKernelGGL(rans_encode_plane_kernel, dim3(cdiv(B, 64 * cw)), dim3(64 * cw), (size_t)cdf_stride * sizeof(EncRec),
                        as_stream(stream), symbols, ssb, ssi, n / plane, plane, cdf_stride, cdf_len, offset,
                        static_cast<const EncRec *>(enc_table), words, cap_words, nwords, status, B);
   } else if (indexes && plane > 0 && plane <= IDX_MAX_ROWS) {
@@ -714,9 +732,19 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   LICOS_REQUIRE(B > 0 && n > 0 && cdf_stride > 1, "rans_decode_batch: bad sizes");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_batch: need indexes or a plane size");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0, "rans_decode_batch: input must be 4-byte aligned");
-  const size_t dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
-  if (!indexes && n % plane == 0 && dec_lds <= 64 * 1024 && cdf_stride <= 65535) {
-    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64)), dim3(64), dec_lds,
+  int cw = coder_waves(B);
+  size_t dec_lds = (size_t)cw * (RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
+  if (dec_lds > 156 * 1024) {  // very long tables: one wave per workgroup
+    cw = 1;
+    dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
+  }
+  if (!indexes && n % plane == 0 && dec_lds <= 156 * 1024 && cdf_stride <= 65535) {
+    static size_t attr_lds = 0;
+    if (dec_lds > attr_lds) {
+      LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_plane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds));
+      attr_lds = dec_lds;
+    }
+    hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64 * cw)), dim3(64 * cw), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);
   } else if (indexes && plane > 0 && plane <= IDX_MAX_ROWS) {

@@ -21,7 +21,7 @@ def collect(path, counter, needle):
         raise SystemExit(f"no {counter} rows for kernels matching {needle!r} in {path}")
     gmax = max(g for g, _, _ in rows)
     vals = [v for g, v, _ in rows if g == gmax]
-    return gmax, vals, rows[0][2]
+    return gmax, vals, [n for g, _, n in rows if g == gmax][0]
 
 
 def main():

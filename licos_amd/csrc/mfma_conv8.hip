@@ -10,7 +10,7 @@
 //   * the weight fragments of a step (double-buffered) are shared by 8 waves instead of 4.
 // Together the LDS-DMA pieces per MFMA drop by ~55 %, which is what the 4-wave kernel's ablation says it is
 // paying for.  One workgroup per CU, two waves per SIMD, one s_barrier per step.
-#include "mfma_common.hpp"
+#include "mfma_deconv8.hpp"
 
 namespace licos {
 
@@ -37,7 +37,13 @@ struct Conv8Geom {
 // lanes read at r - 16 + 18 = r + 2.  Wide layers (Cout = 192: six 32-channel tiles, too many accumulators for two waves
 // per SIMD) run as a.halves channel groups of MT tiles each, one workgroup per group; the input patch of the second
 // group comes out of the XCD's L2.
-template <int MT, int EPI, bool PAIR = false>
+//
+// TILE_EPI (fused GDN, blk16 output - every GDN stage of the analysis transform): the epilogue of the tile kernels
+// (mfma_deconv8.hpp: squares converted ONCE per pixel tile instead of once per 32-channel output tile, gamma / beta /
+// bias in their own LDS region, requested by LDS-DMA in the prologue instead of copied through registers after the K
+// loop; the accumulators start at the bias).  The epilogue is vector-issue bound: 576 fewer vector
+// instructions per wave and tile.
+template <int MT, int EPI, bool PAIR = false, bool TILE_EPI = false>
 __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
   using G = Conv8Geom<MT>;
   constexpr int NT = G::NT;
@@ -45,6 +51,8 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
   half8 *s_even = reinterpret_cast<half8 *>(smem);
   half8 *s_odd = s_even + G::EVEN_PAD;
   half8 *s_wbuf = s_odd + G::ODD_PAD;  // [2][W_GRAN]
+  bf16x8 *s_gamma_t = reinterpret_cast<bf16x8 *>(s_wbuf + 2 * G::W_GRAN);             // TILE_EPI: [GAMMA_GRAN]
+  float *s_bias_t = reinterpret_cast<float *>(s_gamma_t + G::GAMMA_GRAN);              // TILE_EPI: [32 MT] bias, [32 MT] beta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
@@ -70,12 +78,14 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
     base_o[nt] = h * (G::NR_O * G::ROWG) + ty * G::ROWG + r + 2 * img;
   }
   f32x16 acc[MT][NT];
+  if (!TILE_EPI) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
+  }
 
   const size_t plane = (size_t)a.H * a.W;
   const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)(PAIR ? 2 * b : b) * a.Cin16 * plane * 2;
@@ -133,8 +143,32 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
 
   dma_even(0, 0, G::EVEN_Q);
   dma_w(0, 0, 0);
+  if (TILE_EPI) {
+    static_assert(!TILE_EPI || MT == 4, "bias + beta = one 64-lane piece");
+    if (wave == 0) glds16(lane < 32 ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias_t);
+#pragma unroll
+    for (int i = 0; i < (G::GAMMA_GRAN / 64 + 7) / 8; ++i) {
+      const int q = wave + 8 * i;
+      if (q < G::GAMMA_GRAN / 64) glds16(a.gamma + q * 64 + lane, s_gamma_t + q * 64);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (TILE_EPI) {  // accumulators start at the bias: register q of tile mt is channel 32mt + (q&3) + 8(q>>2) + 4h
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(s_bias_t + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt][4 * g + 0] = bv.x;
+          acc[mt][nt][4 * g + 1] = bv.y;
+          acc[mt][nt][4 * g + 2] = bv.z;
+          acc[mt][nt][4 * g + 3] = bv.w;
+        }
+      }
+  }
   int wcur = 0;
   for (int cc = 0; cc < a.Cin16; ++cc) {
 #pragma unroll
@@ -184,6 +218,16 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
       wcur ^= 1;
     }
   }
+  if (TILE_EPI) {
+    const int Cout16 = (a.Cout + 15) >> 4;
+    long pix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      pix[nt] = (oy[nt] >= 0 && oy[nt] < a.Ho && ox[nt] < a.Wo) ? (long)oy[nt] * a.Wo + ox[nt] : -1;
+    tile8_epilogue<MT, NT, EPI>(acc, s_gamma_t, s_bias_t + 32 * MT, a.y_blk + (size_t)(PAIR ? 2 * b + img : b) * Cout16 * a.Ho * a.Wo * 16,
+                                (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    return;
+  }
   const bf16x8 *gam = a.gamma;
   if (EPI == EPI_GDN || EPI == EPI_IGDN) {
     bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
@@ -194,14 +238,15 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
   epilogue_store<MT, NT, EPI>(acc, a, gam, PAIR ? 2 * b + img : b, oy, ox, lane, 32 * mt0);
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool TILE_EPI = false>
 static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
   using G = Conv8Geom<MT>;
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.Wo, G::TW);
   a.tiles_y = cdiv(a.Ho, G::TH);
-  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::TOTAL_GRAN * 16;
-  auto kern = conv5x5s2_mfma8_kernel<MT, EPI>;
+  const size_t lds = TILE_EPI ? (size_t)(G::TOTAL_GRAN + G::GAMMA_GRAN) * 16 + 2 * 32 * MT * sizeof(float)
+                              : (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::TOTAL_GRAN * 16;
+  auto kern = conv5x5s2_mfma8_kernel<MT, EPI, false, TILE_EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -247,7 +292,7 @@ int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
     if (MT == 4 && epi == EPI_RELU) return launch_conv8_pair<4, EPI_RELU>(a, 4, s);
   }
   if (MT != 4 || a.Ho < 16 || a.Wo < 32 || (a.Ho % 16) != 0) return 1;
-  if (epi == EPI_GDN) return launch_conv8<4, EPI_GDN>(a, s);
+  if (epi == EPI_GDN) return (a.y_blk && !a.accum) ? launch_conv8<4, EPI_GDN, true>(a, s) : launch_conv8<4, EPI_GDN>(a, s);
   if (epi == EPI_NONE) return launch_conv8<4, EPI_NONE>(a, s);
   if (epi == EPI_RELU) return launch_conv8<4, EPI_RELU>(a, s);
   return 1;

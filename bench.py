@@ -251,7 +251,7 @@ def train_step_ms(dev, steps=10, world=1):
         res = step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    return {"ms": round(ms, 3), "patches_s": round(16e3 / ms, 1), "loss": round(float(res["loss"]), 4),
+    return {"ms": round(ms, 3), "patches_s": round(16e3 / ms, 1), "loss": round(float(res["loss"].detach()), 4),
             "what": "16 x 13x256x256 patches: forward (noise) + RD loss + backward + clip 1.0 + Adam 1e-4 / aux Adam 1e-3"}, net
 
 
@@ -259,6 +259,10 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_workers(args))
+    # stdout carries ONE JSON line: whatever libraries print there (gloo's rendezvous banner, a build log) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -462,8 +466,8 @@ def main():
             "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
             "stages": stages,
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        print(json.dumps(line), file=json_out)
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

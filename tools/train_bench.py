@@ -43,7 +43,7 @@ for _ in range(steps):
     res = step()
 torch.cuda.synchronize()
 gpu_ms = 1e3 * (time.perf_counter() - t0) / steps
-print("GPU  train step: %.1f ms for %d x %d x 256 x 256 (%.1f patches/s), loss %.4f" % (gpu_ms, B, C, 1e3 * B / gpu_ms, float(res["loss"])))
+print("GPU  train step: %.1f ms for %d x %d x 256 x 256 (%.1f patches/s), loss %.4f" % (gpu_ms, B, C, 1e3 * B / gpu_ms, float(res["loss"].detach())))
 
 if cpu_steps > 0:
     threads = min(os.cpu_count() or 1, 16)

@@ -258,3 +258,25 @@ def test_codec_py_record_layout():
         checkpoint.write_image(io.BytesIO(), out, 0, "bmshj2018-factorized-relu", 1, (64, 96), ids="legacy")
     with pytest.raises(ValueError):
         checkpoint.read_image(io.BytesIO(raw[:20]))
+
+
+def test_bench_flop_accounting_matches_the_survey():
+    """bench.py prices a stage by its convolution MACs plus, when a GDN / IGDN is fused into it, that layer's
+    C x C MACs per output pixel ("conv + GDN MACs x 2").  The eight stages of one 3-channel 256^2
+    tile must add up to the survey's 11.056 GFLOP, and g_a[2]'s convolution alone to its 3.3554 GFLOP."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("licos_bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g_a = [("conv", 3, 128, 256, 256, True), ("conv", 128, 128, 128, 128, True), ("conv", 128, 128, 64, 64, True),
+           ("conv", 128, 192, 32, 32, False)]
+    g_s = [("deconv", 192, 128, 16, 16, True), ("deconv", 128, 128, 32, 32, True), ("deconv", 128, 128, 64, 64, True),
+           ("deconv", 128, 3, 128, 128, False)]
+    total = sum(bench.stage_flops(*s[:5], norm=s[5]) for s in g_a + g_s)
+    assert abs(total - 11.056e9) < 2e6
+    assert abs(bench.stage_flops("conv", 128, 128, 128, 128) - 3.3554432e9) < 1
+    assert abs(bench.stage_flops("deconv", 128, 128, 64, 64) - 3.3554432e9) < 1
+    # the fused norms: 128 x 128 MACs per output pixel
+    assert bench.stage_flops("deconv", 128, 128, 64, 64, norm=True) - bench.stage_flops("deconv", 128, 128, 64, 64) == 2.0 * 128 * 128 * 128 * 128
+    # the first stage as the kernel runs it (3 x 3 stride 1 over the space-to-depth image) is the same work
+    assert bench.stage_flops("conv", 3, 128, 256, 256) == 2.0 * 128 * 128 * 25 * 3 * 128

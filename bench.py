@@ -13,7 +13,7 @@ exits with the workers' status.
 
 Besides the headline the N = 1 line carries (SURVEY.md section 8(d) grid; all timed AFTER the headline region):
   batches            encode+decode ms and tiles/s at B = 1, 16, 64, 1024 (reference batch sizes: eval B = 1,
-                     cfg/raw_merged.toml batch_size 16, test_batch_size 64)
+                     cfg/raw_merged.toml batch_size 16, test_batch_size 64) and at twice the headline's step
   whole_granule      one 1 x 2304 x 2592 band image (eval_script.py's call): as ONE stream, and tiled to 256x256
   decode_from_plain_bytes   the headline decode fed a plain list[bytes] (re-join + staging) instead of PackedStrings
   configs            1-channel (raw split) and 13-channel (raw merged) models, fp32 parity path
@@ -177,6 +177,14 @@ def extras(args, net, x, dev):
     for b in (1, 16, 64, 1024):
         if b <= x.shape[0]:
             out["batches"]["B%d" % b] = timed_codec(net, x[:b].contiguous(), 5 if b >= 1024 else 9, split=True)[0]
+    # twice the headline's step: the un-hidden coder latency (one decode head + one encode tail per compress /
+    # decompress call, ~19 ms whatever the batch) amortised over twice the tiles
+    torch.cuda.empty_cache()  # (the step's 13 GB blocks cannot back 26 GB tensors: without this every run re-allocates)
+    if x.shape[0] >= 16384 and torch.cuda.mem_get_info(dev)[0] > 160 * 2 ** 30:
+        x2 = torch.cat((x, synthetic.tiles(x.shape[0], args.channels, args.size, seed=977, device=dev)))
+        out["batches"]["B%d" % x2.shape[0]] = timed_codec(net, x2, 3, split=True)[0]
+        del x2
+        torch.cuda.empty_cache()
     # the headline decode fed a plain list[bytes] (no PackedStrings shortcut)
     hb = min(x.shape[0], args.batch)
     packed, _, _ = timed_codec(net, x[:hb], 3, split=True)

@@ -138,6 +138,7 @@ static int launch_conv3x3t(const MfmaArgs &a0, hipStream_t s) {
   }
   const long blocks = (long)cdiv(tiles, run) * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "conv3x3s1_f16: grid too large");
+  LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 < (1L << 32), "conv3x3s1_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a, run);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

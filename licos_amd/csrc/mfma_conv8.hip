@@ -253,6 +253,7 @@ static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
     attr_set = true;
   }
   LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
+  LICOS_REQUIRE(!TILE_EPI || (long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 < (1L << 32), "conv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(512), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

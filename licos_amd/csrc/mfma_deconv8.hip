@@ -220,6 +220,7 @@ static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
   }
   const long blocks = (long)a.tiles_x * a.tiles_y * (PAIR ? (a.B + 1) / 2 : a.B);  // a workgroup walks all four phases of its tile
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
+  LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 * (PAIR ? 2 : 1) < (1L << 32), "deconv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

@@ -78,6 +78,15 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
                                                size_t plane_px, int Cout16, const long (&pix)[NT], int lane) {
   constexpr bool NORM = (EPI == EPI_GDN || EPI == EPI_IGDN) && LICOS_ABL != 2;
   const int h = lane >> 5;
+  const unsigned chunk_bytes = (unsigned)plane_px * 32u;  // one 16-channel chunk of the image
+  // the image's base as a scalar pair (it is workgroup-uniform; the readfirstlanes tell the compiler so)
+  const uint64_t y_bits = reinterpret_cast<uint64_t>(y_img);
+  const _Float16 *y_base = reinterpret_cast<const _Float16 *>(
+      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(y_bits >> 32)) << 32) |
+      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)y_bits));  // (the builtin returns int: no sign extension)
+  unsigned pix_off[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) pix_off[nt] = (unsigned)pix[nt] * 32u + 16u * h;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     bf16x8 sq[MT][2];
@@ -146,14 +155,17 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
         }
         const int chunk = 2 * it + gp;
         if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
-          _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
           if (LICOS_STORE_SC1) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 val = {lo[0], lo[1], hi[0], hi[1]};
+            // scalar base + 32-bit byte offset: one vector add per store instead of a 64-bit address (the epilogue is
+            // vector-issue bound; the launchers check that an image's output stays below 4 GB).
             // (the s_nop covers the ISA's manual wait state between a store of more than 64 bits and the next write of
             // its data registers, which the compiler cannot see through the asm)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+            const unsigned off = pix_off[nt] + (unsigned)chunk * chunk_bytes;
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(val), "s"(y_base) : "memory");
           } else {
+            _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
             *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
           }
         }

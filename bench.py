@@ -225,6 +225,9 @@ def extras(args, net, x, dev):
         del n2, xb
     out["configs"] = configs
     torch.cuda.empty_cache()
+    import gc
+    gc.collect()
+    gc.freeze()  # the step is ~690 launches of host work: keep the collector off everything this process built so far
     out["train_step"] = train_step_ms(dev, steps=10)[0]
     return out
 

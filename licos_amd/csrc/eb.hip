@@ -383,6 +383,36 @@ __global__ void gc_build_indexes_kernel(const float *__restrict__ scales, const 
   }
 }
 
+// The same for the coder's interleaved layout [position][stream] (stride_b == 1, stride_i == B): a block owns 64
+// streams x 64 positions and transposes through LDS, so that the scale reads (contiguous along positions) and the
+// index writes (contiguous along streams) are both coalesced - written straight, every 4-byte index lands in a
+// cache line of its own (15.6 ms per 2048 tiles of 13 x 512 x 512 instead of ~1).
+__global__ __launch_bounds__(256) void gc_build_indexes_T_kernel(const float *__restrict__ scales, const float *__restrict__ table,
+                                                                 int levels, float scale_bound, int32_t *__restrict__ indexes,
+                                                                 long si, int B, long n) {
+  __shared__ int32_t tile[64][65];
+  const long i0 = (long)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {  // r: stream within the tile, tx: position
+    const long i = i0 + tx;
+    const int b = b0 + r;
+    int idx = 0;
+    if (i < n && b < B) {
+      const float s = fmaxf(scales[(size_t)b * n + i], scale_bound);
+      idx = levels - 1;
+      for (int t = 0; t < levels - 1; ++t) idx -= (s <= table[t]) ? 1 : 0;
+    }
+    tile[r][tx] = idx;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {  // r: position, tx: stream
+    const long i = i0 + r;
+    const int b = b0 + tx;
+    if (i < n && b < B) indexes[i * si + b] = tile[tx][r];
+  }
+}
+
 // ---- granule pre/post-processing ---------------------------------------------------------
 __global__ void dn12_to_grid8_kernel(const uint16_t *__restrict__ dn, float *__restrict__ out, long n, int full_range) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -570,6 +600,12 @@ int licos_gc_build_indexes(const float *scales, const float *table, int levels, 
                            long stride_b, long stride_i, int B, long n, void *stream) {
   LICOS_REQUIRE(scales && table && indexes && levels > 0 && B > 0 && n > 0, "gc_build_indexes: bad arguments");
   const long total = (long)B * n;
+  if (stride_b == 1 && stride_i >= B && B >= 16 && (n + 63) / 64 < (1L << 31) && (B + 63) / 64 < 65536) {
+    hipLaunchKernelGGL(gc_build_indexes_T_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((B + 63) / 64)), dim3(256), 0,
+                       as_stream(stream), scales, table, levels, scale_bound, indexes, stride_i, B, n);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(gc_build_indexes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), scales, table, levels,
                      scale_bound, indexes, stride_b, stride_i, n, total);

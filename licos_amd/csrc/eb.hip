@@ -142,6 +142,36 @@ __global__ __launch_bounds__(256) void eb_dequantize_T_kernel(const int32_t *__r
   }
 }
 
+// The decoder's case: blk16 fp16 output only.  A block owns one 16-channel chunk x 16 positions x 64 streams: the symbol
+// reads are 256-byte rows along the streams, and every stream's 16 pixels x 16 channels leave as ONE 512-byte run (16 bytes
+// per lane, consecutive lanes consecutive granules) - the kernel above writes blk16 two bytes at a time at a 32-byte
+// stride.  Channels past C (C % 16 != 0) are written as zeros.
+constexpr int DQ_ROW = 16 * 16 + 8;  // halfs per stream in LDS: 528 bytes (16-byte aligned rows)
+__global__ __launch_bounds__(256) void eb_dequantize_blk_T_kernel(const int32_t *__restrict__ symbols, long ssi,
+                                                                  const float *__restrict__ medians, _Float16 *__restrict__ y_blk,
+                                                                  int B, int C, int HW) {
+  __shared__ __attribute__((aligned(16))) _Float16 s_t[64 * DQ_ROW];
+  const int groups = HW / 16;
+  const int c16 = blockIdx.x / groups, p0 = (blockIdx.x - c16 * groups) * 16;
+  const int b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 256; r += 4) {  // r = 16 * channel + position; tx: stream
+    const int c = 16 * c16 + (r >> 4), p = r & 15, b = b0 + tx;
+    float v = 0.f;
+    if (c < C && b < B) v = (float)symbols[((long)c * HW + p0 + p) * ssi + b] + medians[c];
+    s_t[tx * DQ_ROW + p * 16 + (r >> 4)] = (_Float16)v;
+  }
+  __syncthreads();
+  const int C16 = (C + 15) / 16;
+  for (int g = threadIdx.x; g < 64 * 32; g += 256) {  // 32 granules of 16 bytes per stream
+    const int sl = g >> 5, gi = g & 31, b = b0 + sl;
+    if (b < B) {
+      const uint4 val = *reinterpret_cast<const uint4 *>(s_t + sl * DQ_ROW + gi * 8);
+      *reinterpret_cast<uint4 *>(y_blk + (((size_t)b * C16 + c16) * HW + p0) * 16 + gi * 8) = val;
+    }
+  }
+}
+
 // ---- likelihood -------------------------------------------------------------------------------
 __device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -570,6 +600,13 @@ int licos_eb_likelihood(const float *v, const float *packed, const int *filters,
 int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float *medians, float *y_nchw,
                         void *y_blk16, int B, int C, int H, int W, void *stream) {
   LICOS_REQUIRE(symbols && medians && (y_nchw || y_blk16) && B > 0 && C > 0 && H > 0 && W > 0, "eb_dequantize: bad arguments");
+  if (ssb == 1 && B <= 65535 * 64 && !y_nchw && (H * W) % 16 == 0 && (long)(H * W / 16) * ((C + 15) / 16) < (1L << 31) &&
+      ((uintptr_t)y_blk16 & 15) == 0) {
+    hipLaunchKernelGGL(eb_dequantize_blk_T_kernel, dim3((unsigned)((H * W / 16) * ((C + 15) / 16)), (B + 63) / 64), dim3(256), 0,
+                       as_stream(stream), symbols, ssi, medians, static_cast<_Float16 *>(y_blk16), B, C, H * W);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   if (ssb == 1 && B <= 65535 * 64) {
     const long n = (long)C * H * W;
     hipLaunchKernelGGL(eb_dequantize_T_kernel, dim3((unsigned)((n + 63) / 64), (B + 63) / 64), dim3(256), 0, as_stream(stream),

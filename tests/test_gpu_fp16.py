@@ -560,3 +560,21 @@ def test_conv3x3_stage_exact_operands(cin, cout, h, w, relu):
     out = ops.conv3x3s1_f16(xb, wp, bp, None, ops.EPI_RELU if relu else ops.EPI_NONE, cin, cout, out_nchw=True)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("b,c,h,w", [(70, 192, 16, 16), (3, 20, 4, 12), (65, 32, 6, 6), (130, 16, 16, 2)])
+def test_dequantise_to_blk16_layouts_agree(b, c, h, w):
+    """symbols [position][stream] -> y_hat: the coalesced blk16 kernel (H*W % 16 == 0), the element-wise blk16 kernel
+    and the NCHW fp32 output hold the same values (sym + median, one fp16 rounding in blk16)."""
+    g = torch.Generator().manual_seed(b + c)
+    sym = torch.randint(-300, 300, (c * h * w, b), generator=g, dtype=torch.int32).to(DEV)
+    med = torch.randn(c, generator=g).to(DEV)
+    ref = ops.eb_dequantize(sym, 1, b, med, b, c, h, w)                       # NCHW fp32
+    blk = torch.full((b, (c + 15) // 16, h, w, 16), 7.0, device=DEV, dtype=torch.float16)
+    ops.eb_dequantize(sym, 1, b, med, b, c, h, w, want_nchw=False, blk16=blk)
+    assert torch.equal(ops.blk16_to_nchw_f32(blk, c), ref.half().float())
+    if c % 16:  # the channels that pad the last chunk are zeros, whatever the buffer held
+        full = blk.permute(0, 1, 4, 2, 3).reshape(b, -1, h, w)
+        assert float(full[:, c:].abs().max()) == 0.0 or (h * w) % 16 != 0
+    want = sym.t().reshape(b, c, h, w).float() + med.view(1, c, 1, 1)
+    assert torch.equal(ref, want)

@@ -225,18 +225,18 @@ def extras(args, net, x, dev):
         del n2, xb
     out["configs"] = configs
     torch.cuda.empty_cache()
-    import gc
-    gc.collect()
-    gc.freeze()  # the step is ~690 launches of host work: keep the collector off everything this process built so far
     out["train_step"] = train_step_ms(dev, steps=10)[0]
     return out
 
 
 def train_step_ms(dev, steps=10, world=1):
     """cfg/raw_merged.toml's training step on the device (HIP forward and backward, fp32): licos/train.py:186-200."""
+    import gc
     import torch
     import licos_amd
     from licos_amd import synthetic
+    gc.collect()
+    gc.freeze()  # the step is ~690 launches of host work: keep the collector off everything this process built so far
     torch.manual_seed(42)
     net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1).to(dev).train()
     crit = licos_amd.RateDistortionLoss(lmbda=1e-2)

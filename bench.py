@@ -57,24 +57,83 @@ def parse_args():
     return ap.parse_args()
 
 
-def spawn_workers(args):
-    """--gpus N without a launcher: N fresh worker processes, started BEFORE anything here touches the GPU."""
+def spawn_workers(args, limit_s=3000.0):
+    """--gpus N without a launcher: N fresh worker processes, started BEFORE anything here touches the GPU.
+    The parent watches ALL of them: the first rank to exit non-zero (RCCL initialisation, out of memory, a GPU fault)
+    ends the others - left alone they would sit in their next collective until its timeout - and becomes the exit
+    status; so does the wall-clock limit.  The workers form their own process group, which is killed as a whole when the
+    parent is told to stop (SIGTERM / SIGINT) or exits for any reason, so no rank survives holding a GPU."""
+    import atexit
+    import signal
     import socket
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
+    pgid = None
+
+    def kill_group(*_):
+        if pgid is not None:
+            try:
+                os.killpg(pgid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+
+    def on_signal(signum, _frame):
+        kill_group()
+        raise SystemExit(128 + signum)
+
+    atexit.register(kill_group)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(line.decode())
+        log = tempfile.TemporaryFile()  # every rank's stderr is kept: the failing rank's tail is what explains an exit
+        logs.append(log)
+        # rank 0 leads a new process group (same session), the others join it
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=log,
+                             preexec_fn=(lambda g=(pgid or 0): os.setpgid(0, g)))
+        if pgid is None:
+            pgid = p.pid
+        procs.append(p)
+    t0 = time.monotonic()
+    status = 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        failed = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed:
+            status = abs(failed[0][1]) or 1
+            sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % failed[0])
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() - t0 > limit_s:
+            status = 124
+            sys.stderr.write("bench.py: workers still running after %.0f s; stopping them\n" % limit_s)
+            break
+        time.sleep(0.2)
+    if status:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 10
+        while time.monotonic() < deadline and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
+        kill_group()
+        for r, log in enumerate(logs):
+            log.seek(0)
+            tail = log.read().decode("utf-8", "replace")[-1500:]
+            if tail.strip():
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, tail))
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return status
 
 
 def stage_flops(kind, cin, cout, h, w, norm=False):
@@ -223,9 +282,85 @@ def extras(args, net, x, dev):
                 "one_stream": one, "tiled_256": {"ms": round(ts[len(ts) // 2], 3), "tiles": len(coded["strings"][0]),
                                                  "bytes": sum(len(s) for s in coded["strings"][0])}}
         del n2, xb
+    torch.cuda.empty_cache()
+    try:
+        configs["hyperprior_13x512"] = hyperprior_grid(args, dev)
+    except torch.OutOfMemoryError as e:  # reported, never fatal for the headline
+        configs["hyperprior_13x512"] = {"error": str(e)[:200]}
     out["configs"] = configs
     torch.cuda.empty_cache()
     out["train_step"] = train_step_ms(dev, steps=10)[0]
+    return out
+
+
+def hyperprior_grid(args, dev):
+    """BASELINE configs[4]: bmshj2018_hyperprior q=5 on 13-band 512 x 512 tiles (licos/model_utils.py:20-24 admits the
+    model), compress() + decompress() through the module API at 2048 / 4096 / 256 tiles per call: tiles/s with the
+    encode / decode split, per-stage device times, the dominant MFMA kernel against the fp16 roof, and the serial
+    coders' latency per symbol (a y stream is 196 608 symbols, one GPU lane each)."""
+    import torch
+    import licos_amd
+    from licos_amd import checkpoint, codec, engine, synthetic
+    torch.manual_seed(42)
+    net = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5).to(dev).eval().set_precision("fp16")
+    wfile = os.path.join(ROOT, "licos_amd", "weights", "hyperprior_q5_c13.pth.tar")
+    if os.path.exists(wfile) and args.weights == "trained":
+        meta = checkpoint.load_checkpoint(wfile, net)
+        weights = "trained with the repo's own step: %s" % meta.get("recipe", os.path.basename(wfile))
+    else:
+        with torch.no_grad():
+            synthetic.make_trained_like(net, seed=0)
+        weights = "synthetic trained-like (seeded)"
+    out = {"weights": weights, "gflop_per_tile": 54.76}
+    free = torch.cuda.mem_get_info(dev)[0]
+    sizes = [b for b in (2048, 4096, 256) if b * 2 * 13 * 512 * 512 * 4 * 1.6 < free]
+    x = synthetic.tiles(max(sizes), 13, 512, seed=300, kind="s2-merged", device=dev)
+    for b in sizes:
+        xb = x[:b]
+        if b == 2048 or (2048 not in sizes and b == sizes[0]):
+            engine.stage_events, codec.coder_events = {}, {}
+        res, c, d = timed_codec(net, xb, 3, split=True)
+        res["gflops_frac_of_peak"] = round(54.76e9 * res["tiles_s"] / 1e12 / PEAK_F16_TFLOPS, 4)
+        if engine.stage_events is not None:
+            ev, cev = engine.stage_events, codec.coder_events
+            engine.stage_events = codec.coder_events = None
+            nbytes = sum(len(s) for lst in c["strings"] for s in lst)
+            res["bpp_actual"] = round(nbytes * 8.0 / (b * 512 * 512), 4)
+            res["psnr_db"] = round(licos_amd.metrics.compute_psnr(d["x_hat"], xb), 3)
+            stages, dom = {}, None
+            for key, evs in ev.items():
+                ms_all = [e0.elapsed_time(e1) for e0, e1 in evs]
+                ms = sum(ms_all) / len(ms_all)
+                fl = stage_flops(*key[:5], norm=key[6]) * key[5]
+                stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
+                if key[1] >= 128 and key[2] >= 128 and (dom is None or sum(ms_all) > dom[1]):
+                    dom = (key, sum(ms_all), ms, fl)
+            res["stages"] = stages
+            if dom:
+                key, _, ms, fl = dom
+                res["roofline"] = {"kernel": "%s_%d_%d_%dx%d" % key[:5], "bound": "mfma", "achieved": round(fl / ms / 1e9, 2),
+                                   "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+                                   "frac_conv_only": round(stage_flops(*key[:5]) * key[5] / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+                                   "avg_launch_ms": round(ms, 4), "tiles_per_launch": key[5], "traffic": None}
+            nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
+            coders = {}
+            for key, evs in cev.items():
+                ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
+                coders[key] = {"ms_per_launch": round(ms, 3), "ns_per_symbol": round(1e6 * ms / nsym[key[0]], 1), "launches": len(evs)}
+            res["coders"] = coders
+        out["B%d" % b] = res
+        del c, d
+    # "matched": the trained point against the CPU oracle on the same two tiles
+    if not args.no_cpu_baseline:
+        from oracle import model as om
+        sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
+        x2 = x[:2].contiguous()
+        with torch.no_grad():
+            o = net(x2)
+        ref = om.hyper_forward(x2.cpu(), sd)
+        out["quality_match"] = {"tiles": 2, "bpp_gpu": round(licos_amd.metrics.compute_bpp(o), 5), "bpp_oracle": round(om.compute_bpp(ref), 5),
+                                "psnr_gpu": round(licos_amd.metrics.compute_psnr(o["x_hat"].clamp(0, 1), x2), 4),
+                                "psnr_oracle": round(om.compute_psnr(ref["x_hat"].clamp(0, 1), x2.cpu()), 4)}
     return out
 
 
@@ -305,8 +440,9 @@ def main():
     net = net.to(dev).eval().set_precision(args.precision)
     net.chunk = args.chunk
     weights = "synthetic trained-like (seeded)"
-    wfile = os.path.join(ROOT, "licos_amd", "weights", "factorized_q%d_c%d.pth.tar" % (args.quality, args.channels))
-    if args.weights == "trained" and args.model == "bmshj2018-factorized" and os.path.exists(wfile):
+    short = {"bmshj2018-factorized": "factorized", "bmshj2018-factorized-relu": "factorized_relu", "bmshj2018-hyperprior": "hyperprior"}
+    wfile = os.path.join(ROOT, "licos_amd", "weights", "%s_q%d_c%d.pth.tar" % (short.get(args.model, args.model), args.quality, args.channels))
+    if args.weights == "trained" and os.path.exists(wfile):
         from licos_amd import checkpoint
         meta = checkpoint.load_checkpoint(wfile, net)
         weights = "trained with the repo's own step (tools/train_weights.py): %s" % meta.get("recipe", os.path.basename(wfile))

@@ -254,6 +254,38 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/
                             int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int32_t *symbols,
                             int32_t *status, int B, void *stream);
 
+/* --- the scale-conditioned fast path ([CAI] entropy_models.py GaussianConditional.compress / decompress: one CDF row
+ * per ELEMENT, chosen by the predicted scale; rans_interface.cpp encode_with_indexes / decode_with_indexes) -------------
+ * Same streams as the generic entry points above, byte for byte; the work that does not depend on the coder state is
+ * split off into throughput kernels so that the serial, one-lane-per-stream part touches no table (encode) or one
+ * 8-byte LDS record (decode) per symbol.  No means (CompressAI's `means=None`): symbols are round(y).
+ *
+ * licos_gc_encode_prepare: y, scales [B][n] fp32 (NCHW order) -> rec [n][B] 16-byte records, aux [n][B] int32 (raw
+ * escape values).  scale_table: the `levels` sorted scales of build_indexes(); enc_table: licos_rans_build_enc_table's
+ * output on the device.  licos_rans_encode_records: the serial part; words / nwords / status as licos_rans_encode_batch.
+ *
+ * licos_rans_image_build (host): turns the integer CDF table into the decoder image (meta, bucket records, 16-bit
+ * symbol starts; licos_amd/csrc/rans_image.hpp) of at most budget_bytes (licos_rans_image_budget(waves) = what fits
+ * in LDS beside the decode kernel's rings).  row_weight: optional expected use of each row (NULL = uniform).
+ * licos_rans_image_lookup (host, test hook): symbol and [lo, hi) for a 16-bit value; returns 1 if the slow search ran.
+ *
+ * licos_gc_decode_prepare: scales [B][n] -> row bytes idx16 [ceil(n/16)][B][16].  licos_rans_decode_image: the serial
+ * part; `image` on the device, `image_host_header` = the first 32 bytes of the same image on the host. */
+int licos_gc_encode_prepare(const float *y, const float *scales, const float *scale_table, int levels, float scale_bound,
+                            const void *enc_table, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, void *rec,
+                            int32_t *aux, int B, long n, void *stream);
+int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint32_t *words, int cap_words, int32_t *nwords,
+                              int32_t *status, int B, void *stream);
+long licos_rans_image_budget(int waves);
+int licos_rans_image_build(const int32_t *cdf_host, const int32_t *cdf_len_host, const int32_t *offset_host, int rows, int stride,
+                           const float *row_weight, long budget_bytes, void *image_out_host, long *image_bytes);
+int licos_rans_image_lookup(const void *image_host, int row, int cf, int32_t *symbol_lo_hi /*[3]*/);
+int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16, int B,
+                            long n, void *stream);
+int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const void *idx16, long n, const void *image,
+                            const void *image_host_header, int32_t *symbols, long sym_stride_b, long sym_stride_i,
+                            int32_t *status, int B, void *stream);
+
 /* ------------------------------------------------------- federated averaging
  * Replaces the file-based pair-wise blend of /root/reference/licos/federation_utils.py:47-53 by one
  * collective over a flat fp32 bucket of the whole floating state: every rank scales its bucket by its

@@ -21,6 +21,22 @@ _streams = {}
 timings = None
 
 
+# Optional device timing of the serial coder launches (bench.py): when a dict, each one is bracketed by HIP events on
+# the stream it runs on; key = "z_encode" | "y_encode" | "z_decode" | "y_decode" -> [(start, end)].
+coder_events = None
+
+
+def _timed_coder(key, fn):
+    if coder_events is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    coder_events.setdefault(key, []).append((e0, e1))
+    return out
+
+
 class _Section:
     def __init__(self):
         self.t = None
@@ -199,5 +215,192 @@ def decompress_fp16(net, strings, shape, chunk=1024):
         engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
     sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
+        raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+    return {"x_hat": x_hat}
+
+
+# ------------------------------------------------------------------------------------------------ scale hyperprior
+def _drain(dev, copy, coded, parts):
+    """One pipeline chunk's strings: `parts` = [(words, nwords, status)] per string list (all of the same n streams).
+    One D2H of the lengths, compaction of every list into ONE packed buffer, one D2H of that.  Returns
+    (overflow flag, page-locked tensor, [np.int64 offsets [n+1]] per list) with the offsets absolute in the buffer."""
+    with torch.cuda.stream(copy):
+        copy.wait_event(coded)
+        n = parts[0][1].numel()
+        meta = torch.cat([t for (_, nw, st) in parts for t in (nw, st)]).cpu().numpy()  # synchronises the copy stream only
+        offs, base = [], 0
+        for k in range(len(parts)):
+            seg = meta[k * (n + 1):(k + 1) * (n + 1)]
+            if seg[n]:
+                return True, None, None
+            off = np.empty(n + 1, dtype=np.int64)
+            off[0] = base
+            np.cumsum(seg[:n].astype(np.int64) * 4, out=off[1:])
+            off[1:] += base
+            base = int(off[-1])
+            offs.append(off)
+        packed = torch.empty(max(base, 4), device=dev, dtype=torch.uint8)
+        for (words, nwords, _), off in zip(parts, offs):
+            ops.rans_compact(words, nwords, torch.from_numpy(off).to(dev), 0, out=packed)
+        host_t = torch.empty(max(base, 4), dtype=torch.uint8, pin_memory=True)
+        host_t.copy_(packed, non_blocking=True)
+        copy.synchronize()
+    return False, host_t, offs
+
+
+def hyper_fast_path(net, batch):
+    """The chunk-pipelined scale-hyperprior codec applies: device coder placement and a decoder image that fits LDS."""
+    return (not ops.host_coder_preferred(batch)) and net.gaussian_conditional.coder_image() is not None
+
+
+def compress_hyper(net, x, chunk=512, cap_words=None):
+    """ScaleHyperprior.compress ([CAI] models/google.py) for a large batch, either precision: per chunk the four
+    transforms run on the main stream, then ONE throughput kernel turns (y, scales) into per-symbol encoder records
+    (licos_gc_encode_prepare) and the two serial coder kernels (z: plane coder, y: record coder) run on the side stream
+    under the next chunk's transforms.  z_hat is round(z - median) + median computed directly: the reference obtains it
+    by decoding the z string it has just written, which returns exactly those integers."""
+    eb, gc = net.entropy_bottleneck, net.gaussian_conditional
+    zcdf, zlen, zoff, ztab = eb.coder_tables()
+    ycdf, ylen, yoff, ytab = gc.coder_tables()
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise ValueError("licos_amd: compress expects a float32 (B, C, H, W) tensor")
+    x = x.contiguous()
+    B = x.shape[0]
+    dev = x.device
+    main = torch.cuda.current_stream(dev)
+    side, copy = _stream(dev, "coder"), _stream(dev, "copy")
+    med = eb.medians_vec()
+    bound = gc.lower_bound_scale.bound_value
+    queued, shape = [], None
+    for (s0, n) in _chunks(B, chunk):
+        y = net.g_a(x[s0:s0 + n])
+        z = net.h_a(y)
+        if shape is None:
+            shape = tuple(z.shape[-2:])
+            ny, nz, zplane = y[0].numel(), z[0].numel(), z[0, 0].numel()
+            ycap = (ny // 2 + 64) if cap_words is None else cap_words
+            zcap = nz // 2 + 64 if cap_words is None else 2 * nz + 8
+        zsym = torch.empty((nz, n), device=dev, dtype=torch.int32)
+        ops.eb_quantize(z, med, "symbols", symbols=zsym, sym_stride_b=1, sym_stride_i=n)
+        z_hat = ops.eb_quantize(z, med, "dequantize")
+        scales = net.h_s(z_hat)
+        rec, aux = ops.gc_encode_prepare(y.contiguous(), scales.contiguous(), gc.scale_table, bound, ytab, ylen, yoff, ycdf.shape[1])
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            zpart = _timed_coder("z_encode", lambda: ops.rans_encode_batch(zsym, 1, n, nz, zplane, zcdf, zlen, zoff, ztab, zcap, n))
+            ypart = _timed_coder("y_encode", lambda: ops.rans_encode_records(rec, aux, ycap))
+            coded = torch.cuda.Event()
+            coded.record(side)
+        queued.append((s0, n, (y, z, zsym, rec, aux), ypart, zpart, coded))
+        del y, z, zsym, z_hat, scales, rec, aux
+    ys, zs = [None] * B, [None] * B
+    segments = []
+    overflow = False
+    for i, (s0, n, keep, ypart, zpart, coded) in enumerate(queued):
+        overflow, host_t, offs = _drain(dev, copy, coded, [ypart, zpart])
+        if overflow:
+            break
+        queued[i] = None  # the chunk's records (20 B per symbol) and scratch go back to the allocator
+        del keep, ypart, zpart
+        mv = memoryview(host_t.numpy())
+        yo, zo = offs
+        ys[s0:s0 + n] = [bytes(mv[yo[i]:yo[i + 1]]) for i in range(n)]
+        zs[s0:s0 + n] = [bytes(mv[zo[i]:zo[i + 1]]) for i in range(n)]
+        segments.append((s0, n, host_t, yo, zo))
+    if overflow:
+        torch.cuda.synchronize(dev)
+        if cap_words is not None:
+            raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
+        del queued
+        return compress_hyper(net, x, chunk=chunk, cap_words=2 * ny + 8)
+    main.wait_stream(side)
+    main.wait_stream(copy)
+    ysegs = [(s0, n, t, yo) for (s0, n, t, yo, _) in segments]
+    zsegs = [(s0, n, t, zo) for (s0, n, t, _, zo) in segments]
+    return {"strings": [PackedStrings(ys, ysegs), PackedStrings(zs, zsegs)], "shape": torch.Size(shape)}
+
+
+def _upload(strs, pieces, dev):
+    """Per piece (s0, n): (device bytes, device int64 offsets [n+1]) of strs[s0:s0+n] - straight from compress()'s
+    page-locked segments when `strs` still is what compress() returned, else re-joined through a staging buffer."""
+    from .entropy_models import EntropyBottleneck
+    if isinstance(strs, PackedStrings) and strs.still_packed() and [(s, n) for (s, n, _, _) in strs.segments] == list(pieces):
+        out = []
+        for (_, n, host_t, off) in strs.segments:
+            lo, hi = int(off[0]), int(off[-1])
+            lo4 = lo & ~3
+            data = host_t[lo4: max(hi, lo4 + 4)].to(dev, non_blocking=True)
+            out.append((data, torch.from_numpy(off - lo4).to(dev, non_blocking=True)))
+        return out
+    return [EntropyBottleneck.pack_strings(strs[s0:s0 + n], dev) for (s0, n) in pieces]
+
+
+def decompress_hyper(net, strings, shape, chunk=512):
+    """ScaleHyperprior.decompress for a large batch: every tile's z string is decoded in one launch, then per chunk
+    h_s + the row-byte kernel run on the main stream and the chunk's y decoder on the side stream - ALL chunks' decoders
+    are in flight before the first synthesis transform starts, which then overlaps the later chunks' decoding."""
+    from . import engine
+    eb, gc = net.entropy_bottleneck, net.gaussian_conditional
+    zcdf, zlen, zoff, _ = eb.coder_tables()
+    image_dev, image_host = gc.coder_image()
+    assert isinstance(strings, list) and len(strings) == 2
+    ystrs, zstrs = strings
+    B = len(ystrs)
+    if len(zstrs) != B:
+        raise ValueError("licos_amd: y and z string lists differ in length")
+    dev = zcdf.device
+    h, w = int(shape[0]), int(shape[1])
+    N, M = net.N, net.M
+    nz, zplane = N * h * w, h * w
+    ny = M * (4 * h) * (4 * w)
+    main = torch.cuda.current_stream(dev)
+    side = _stream(dev, "coder")
+    med = eb.medians_vec()
+    bound = gc.lower_bound_scale.bound_value
+    pieces = [(s0, n) for (s0, n) in _chunks(B, chunk)]
+    # PackedStrings carry compress()'s own chunking; decode in those pieces when it is intact
+    if isinstance(ystrs, PackedStrings) and ystrs.still_packed():
+        pieces = [(s0, n) for (s0, n, _, _) in ystrs.segments]
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    zsym = torch.empty((nz, B), device=dev, dtype=torch.int32)
+    zup = _upload(zstrs, pieces, dev)
+    for (s0, n), (data, off) in zip(pieces, zup):
+        _timed_coder("z_decode", lambda: ops.rans_decode_batch(data, off, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, n, sym_offset=s0,
+                                                               status=status, off_offset=0))
+    z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
+    yup = _upload(ystrs, pieces, dev)
+    fp16 = net.precision == "fp16"
+    st = engine.stages(net.g_s)
+    cout = st[-1][0].out_channels
+    x_hat = torch.empty((B, cout, 64 * h, 64 * w), device=dev, dtype=torch.float32)
+    zeros = torch.zeros(M, device=dev, dtype=torch.float32)
+    events, keep = [], []
+    for (s0, n), (data, off) in zip(pieces, yup):
+        scales = net.h_s(z_hat[s0:s0 + n])
+        idx16 = ops.gc_decode_prepare(scales.contiguous(), gc.scale_table, bound)
+        sym = torch.empty((ny, n), device=dev, dtype=torch.int32)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            _timed_coder("y_decode", lambda: ops.rans_decode_image(data, off, idx16, ny, image_dev, image_host, sym, 1, n, n, status=status))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        events.append(ev)
+        keep.append((data, off, idx16, sym))
+        del scales
+    for (s0, n), ev, (_, _, _, sym) in zip(pieces, events, keep):
+        main.wait_event(ev)
+        if fp16:
+            y_blk = torch.empty((n, M // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16) if M % 16 == 0 else \
+                torch.zeros((n, (M + 15) // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16)
+            ops.eb_dequantize(sym, 1, n, zeros, n, M, 4 * h, 4 * w, want_nchw=False, blk16=y_blk)
+            engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+        else:
+            y_hat = ops.eb_dequantize(sym, 1, n, zeros, n, M, 4 * h, 4 * w)
+            x_hat[s0:s0 + n] = net.g_s(y_hat).clamp_(0, 1)
+    if int(status.item()) != 0:  # synchronises; also keeps the side stream's tensors alive until it is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
     return {"x_hat": x_hat}

@@ -1,0 +1,565 @@
+// Scale-conditioned rANS path (CompressAI GaussianConditional.compress / decompress, BASELINE config 5): every symbol
+// of a tile's y stream (192 x 32 x 32 = 196 608 of them for a 512 x 512 tile) is coded with the CDF row its predicted
+// scale selects.  The stream format is rans.hip's (bit-exact with rans_interface.cpp); what differs is where the time
+// goes: a lane owns a stream and the recurrence is strictly serial, so a launch lasts n_symbols x (latency of one
+// state -> state step) whatever the batch, and everything that can be computed WITHOUT the coder state is moved out of
+// that chain into throughput kernels that fill the chip:
+//
+//   encode   gc_encode_prepare_kernel   (y, scales) -> one 16-byte encoder record per symbol (table row by scale,
+//                                       symbol by rounding, escape folded in), transposed to [position][stream]
+//            rans_encode_records_kernel the serial part: renormalise + reciprocal multiply per record, no table at all
+//   decode   gc_decode_prepare_kernel   scales -> one table-row byte per symbol, [block of 16][stream][16]
+//            rans_decode_image_kernel   the serial part: per symbol ONE 8-byte LDS read of the decoder image
+//                                       (rans_image.hpp) resolves symbol and interval; row bytes arrive by LDS-DMA two
+//                                       blocks ahead and decoded symbols leave by counted stores, so the loop never
+//                                       waits for memory
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "common.hpp"
+#include "rans_image.hpp"
+
+namespace licos {
+namespace gc {
+
+constexpr uint64_t RANS_L = 1ull << 31;
+constexpr int SYM_BLK = 16;          // symbols per decode block (= one 16-byte row-index granule per stream)
+constexpr int RING = 32, RING_LOW = 16;  // LDS ring of stream words per lane; a block takes at most SYM_BLK off it between checks
+constexpr int IDEPTH = 4;            // LDS-DMA slots of row-index granules per wave
+constexpr uint32_t REC_ESCAPE = 0x80000000u;  // flag in EncRec's (freq | shift << 16) dword: raw value in the aux plane
+
+struct EncRec { uint64_t rcp; uint32_t bias; uint16_t freq; uint16_t shift; };
+
+// ---------------------------------------------------------------------------------------------- encode: prepare
+__device__ inline int scale_row(float s, const float *__restrict__ table, int levels, float bound) {
+  s = fmaxf(s, bound);
+  int idx = levels - 1;
+  for (int t = 0; t < levels - 1; ++t) idx -= (s <= table[t]) ? 1 : 0;
+  return idx;
+}
+
+// block = 64 streams x 32 positions; latents and scales are read along positions (NCHW rows), records leave along
+// streams (the coder's lanes), through LDS
+__global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__restrict__ y, const float *__restrict__ scales,
+                                                               const float *__restrict__ table, int levels, float bound,
+                                                               const uint4 *__restrict__ enc_table, int cdf_stride,
+                                                               const int32_t *__restrict__ cdf_len,
+                                                               const int32_t *__restrict__ offset, uint4 *__restrict__ rec,
+                                                               int32_t *__restrict__ aux, int B, long n) {
+  __shared__ uint4 t_rec[32][65];
+  __shared__ int32_t t_aux[32][65];
+  const long i0 = (long)blockIdx.x * 32;
+  const int b0 = blockIdx.y * 64;
+  {
+    const int p = threadIdx.x & 31;
+    const long i = i0 + p;
+    for (int r = threadIdx.x >> 5; r < 64; r += 8) {
+      const int b = b0 + r;
+      uint4 e = make_uint4(0, 0, 0, 0);
+      int32_t raw = 0;
+      if (i < n && b < B) {
+        const size_t at = (size_t)b * n + i;
+        const int c = scale_row(scales[at], table, levels, bound);
+        const int32_t max_value = cdf_len[c] - 2;
+        int32_t v = (int32_t)rintf(y[at]) - offset[c];  // round-half-to-even, as torch.round
+        bool esc = false;
+        if (v < 0) { raw = -2 * v - 1; v = max_value; esc = true; }
+        else if (v >= max_value) { raw = 2 * (v - max_value); v = max_value; esc = true; }
+        e = enc_table[(size_t)c * cdf_stride + v];
+        if (esc) e.w |= REC_ESCAPE;
+      }
+      t_rec[p][r] = e;
+      t_aux[p][r] = raw;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = threadIdx.x & 63;
+    const int b = b0 + r;
+    for (int p = threadIdx.x >> 6; p < 32; p += 4) {
+      const long i = i0 + p;
+      if (i < n && b < B) {
+        rec[(size_t)i * B + b] = t_rec[p][r];
+        aux[(size_t)i * B + b] = t_aux[p][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- encode: serial part
+struct WordSink {
+  uint32_t *words;
+  int B, b, wp;
+  bool overflow;
+  __device__ inline void put(uint32_t w) {
+    if (wp > 0) { --wp; words[(size_t)wp * B + b] = w; }
+    else overflow = true;
+  }
+  // branch-free: the word is always stored to the next free slot, the slot is claimed only when `emit` is set
+  __device__ inline void put_if(bool emit, uint32_t w) {
+    const int slot = wp > 0 ? wp - 1 : 0;
+    words[(size_t)slot * B + b] = w;
+    overflow = overflow || (emit && wp <= 0);
+    wp = emit ? slot : wp;
+  }
+};
+
+__device__ inline void put_bits4(uint64_t &x, WordSink &sink, uint32_t val) {
+  if (x >= (1ull << 59)) { sink.put((uint32_t)x); x >>= 32; }  // Rans64EncPutBits, nbits = 4
+  x = (x << 4) | val;
+}
+
+constexpr int ENC_BATCH = 8;
+
+__global__ __launch_bounds__(256) void rans_encode_records_kernel(const uint4 *__restrict__ rec, const int32_t *__restrict__ aux,
+                                                                 long n, uint32_t *__restrict__ words, int cap_words,
+                                                                 int32_t *__restrict__ nwords, int32_t *__restrict__ status,
+                                                                 int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;  // no barrier below
+  WordSink sink{words, B, b, cap_words, false};
+  uint64_t x = RANS_L;
+  const uint4 *rp = rec + b;
+  const int32_t *ap = aux + b;
+  uint4 nxt[ENC_BATCH];
+  auto fetch = [&](long i1) {
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) {
+      const long i = i1 - 1 - k;
+      nxt[k] = (i >= 0) ? rp[(size_t)i * B] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto code = [&](auto full_c, long i1, int nb, bool more) {
+    constexpr bool FULL = decltype(full_c)::value;
+    uint4 cur[ENC_BATCH];
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) cur[k] = nxt[k];
+    if (more) fetch(i1 - ENC_BATCH);  // the next batch's records: their latency hides under this batch's chain
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) {
+      if (!FULL && k >= nb) break;
+      const bool escape = (cur[k].w & REC_ESCAPE) != 0;
+      if (__any(escape)) {  // uniform and rare: some stream codes a value outside its row's range
+        if (escape) {
+          const uint32_t raw = (uint32_t)ap[(size_t)(i1 - 1 - k) * B];
+          int nbyp = 0;
+          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+          // coding order is [symbol, count nibble, raw nibbles low -> high]; emitted reversed
+          for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+          put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+        }
+      }
+      const uint32_t f16 = cur[k].w & 0xFFFFu;
+      const uint32_t freq = f16 ? f16 : 65536u;
+      const uint32_t shift = (cur[k].w >> 16) & 0x7FFFu;
+      const uint64_t rcp = ((uint64_t)cur[k].y << 32) | cur[k].x;
+      // x >= freq << 47 compares the high words (the bound's low 47 bits are 0)
+      const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
+      sink.put_if(emit, (uint32_t)x);
+      x = emit ? (x >> 32) : x;
+      const uint64_t q = __umul64hi(x, rcp) >> shift;
+      x = x + cur[k].z + q * (uint64_t)(65536u - freq);
+    }
+  };
+  fetch(n);
+  long i1 = n;
+  for (; i1 >= ENC_BATCH; i1 -= ENC_BATCH) code(std::true_type{}, i1, ENC_BATCH, i1 - ENC_BATCH > 0);
+  if (i1 > 0) code(std::false_type{}, i1, (int)i1, false);
+  sink.put((uint32_t)(x >> 32));
+  sink.put((uint32_t)x);
+  nwords[b] = cap_words - sink.wp;
+  if (sink.overflow) atomicOr(status, 1);
+}
+
+// ---------------------------------------------------------------------------------------------- decode: prepare
+// scales -> row byte per symbol in granules of 16 positions: idx16[block][stream][16].  block = 64 streams x 64 positions.
+__global__ __launch_bounds__(256) void gc_decode_prepare_kernel(const float *__restrict__ scales, const float *__restrict__ table,
+                                                               int levels, float bound, uint4 *__restrict__ idx16, int B, long n) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];
+  const long i0 = (long)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 64;
+  {
+    const int p = threadIdx.x & 63;
+    const long i = i0 + p;
+    for (int r = threadIdx.x >> 6; r < 64; r += 4) {
+      const int b = b0 + r;
+      int c = 0;
+      if (i < n && b < B) c = scale_row(scales[(size_t)b * n + i], table, levels, bound);
+      tile[r][p] = (uint8_t)c;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int b = b0 + r;
+    const long blk = i0 / 16 + q;
+    if (b < B && blk * 16 < n) idx16[(size_t)blk * B + b] = *reinterpret_cast<const uint4 *>(&tile[r][q * 16]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- decode: serial part
+// Per-lane ring of the next stream words in LDS ([slot][lane]); see rans.hip RingSource - same discipline, half the depth.
+struct RingSource {
+  const uint32_t *p;
+  uint32_t *ring;
+  int nw, rd, filled, last;
+  bool over;
+  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
+    p = n > 0 ? ptr : fallback; nw = n; last = n > 0 ? n - 1 : 0; ring = lane_ring; rd = 0; over = false; filled = 0;
+    top_up();
+    top_up();
+  }
+  __device__ inline void top_up() {
+    uint32_t w[16];
+    const bool room = filled - rd <= RING - 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = filled + j;
+      const uint32_t *a = p + (i < last ? i : last);  // past the end: re-read the last word, zeroed below
+      asm volatile("global_load_dword %0, %1, off" : "=v"(w[j]) : "v"(a));
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
+                   "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+    if (room) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ring[((filled + j) & (RING - 1)) * 64] = (filled + j < nw) ? w[j] : 0u;
+      filled += 16;
+    }
+  }
+  __device__ inline void refill_if_low() {
+    if (__any(filled - rd <= RING_LOW)) top_up();
+  }
+  __device__ inline uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
+  __device__ inline void advance(bool used) {
+    over = over || (used && rd >= nw);
+    rd += used ? 1 : 0;
+  }
+  __device__ inline uint32_t next() {
+    if (rd >= nw) over = true;
+    const uint32_t w = ring[(rd & (RING - 1)) * 64];
+    ++rd;
+    return w;
+  }
+};
+
+__device__ inline uint32_t get_bits4(uint64_t &x, RingSource &src) {
+  const uint32_t val = (uint32_t)(x & 15u);
+  x >>= 4;
+  if (x < RANS_L) x = (x << 32) | src.next();
+  return val;
+}
+
+// 16 B per lane, global -> LDS, no register round trip (LDS address = wave base + lane * 16); counted in vmcnt only.
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(m0v)
+               : "memory");
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uint8_t *__restrict__ in,
+                                                                       const int64_t *__restrict__ byte_off,
+                                                                       const uint4 *__restrict__ idx16, long n,
+                                                                       const uint4 *__restrict__ image, int image_bytes,
+                                                                       int off_meta, int off_rec, int off_cdf,
+                                                                       int32_t *__restrict__ symbols, long ssb, long ssi,
+                                                                       int32_t *__restrict__ status, int B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem) + wave * (RING * 64);
+  uint4 *s_idx = reinterpret_cast<uint4 *>(smem + WAVES * RING * 64 * 4) + wave * (IDEPTH * 64);
+  unsigned char *s_img = smem + WAVES * (RING * 64 * 4 + IDEPTH * 64 * 16);
+  for (int e = tid; e < image_bytes / 16; e += 64 * WAVES) reinterpret_cast<uint4 *>(s_img)[e] = image[e];
+  __syncthreads();
+  const int wave_b0 = (blockIdx.x * WAVES + wave) * 64;
+  if (wave_b0 >= B) return;  // (no barrier below) a wave without streams would also break the store count the waits rely on
+  const ImageMeta *s_meta = reinterpret_cast<const ImageMeta *>(s_img + off_meta);
+  const uint2 *s_rec = reinterpret_cast<const uint2 *>(s_img + off_rec);
+  const uint16_t *s_cdf = reinterpret_cast<const uint16_t *>(s_img + off_cdf);
+  const bool live = wave_b0 + lane < B;
+  const int b = live ? wave_b0 + lane : B - 1;  // idle lanes shadow the last stream; they never store
+  RingSource src;
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane,
+           reinterpret_cast<const uint32_t *>(byte_off));
+  uint64_t x = (uint64_t)src.next();
+  x |= (uint64_t)src.next() << 32;
+  int32_t *sp = symbols + (size_t)b * ssb;
+  const long nblk = (n + SYM_BLK - 1) / SYM_BLK;
+  const uint4 *ip = idx16 + b;  // granule of block j at ip[j * B]
+  // Row-index granules travel global -> LDS two blocks ahead.  vmcnt discipline of a block j (all vector-memory
+  // operations of the loop are issued by this code, in this order):
+  //     wait for granule j | read it | request granule j + 2 | SYM_BLK symbols | SYM_BLK stores
+  // Granule j was requested in block j - 2; issued after it: that block's stores, granule j + 1's request, block
+  // j - 1's stores.  `s_waitcnt vmcnt(SYM_BLK)` leaves exactly the youngest SYM_BLK operations - block j - 1's stores,
+  // every block but the last stores all SYM_BLK - in flight and so guarantees granules j and j + 1 have landed, without
+  // waiting for stores issued a moment ago.  (A ring refill drains everything; that only makes the counts smaller.)
+  dma16(ip, s_idx);
+  if (nblk > 1) dma16(ip + (size_t)B, s_idx + 64);
+  for (long j = 0; j < nblk; ++j) {
+    src.refill_if_low();
+    if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    static_assert(SYM_BLK == 16, "the counted wait above is written for 16 stores per block");
+    const uint4 g = s_idx[(j & (IDEPTH - 1)) * 64 + lane];
+    if (j + 2 < nblk) dma16(ip + (size_t)(j + 2) * B, s_idx + ((j + 2) & (IDEPTH - 1)) * 64);
+    const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+    int32_t outv[SYM_BLK];
+    const long i0 = j * SYM_BLK;
+    const int nb = (n - i0) < SYM_BLK ? (int)(n - i0) : SYM_BLK;
+    auto decode_block = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+      for (int k = 0; k < SYM_BLK; ++k) {
+        outv[k] = 0;
+        if (!FULL && k >= nb) break;
+        const uint32_t c = (gw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+        const ImageMeta m = s_meta[c];
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+        // the next stream word is read before it is known to be needed: its LDS latency runs beside the lookup's
+        const uint32_t w_next = src.peek();
+        int s;
+        uint32_t lo, him;
+        bool fb;
+        image_lookup(m, s_rec, s_cdf, cf, s, lo, him, fb);
+        x = (uint64_t)(him + 1u - lo) * (x >> 16) + cf - lo;
+        const bool need = x < RANS_L;
+        x = need ? ((x << 32) | w_next) : x;
+        src.advance(need);
+        const int max_value = (int)(m.cdf_base_max >> 16);
+        int32_t value = s;
+        if (__any(s == max_value)) {  // uniform and rare: some stream hit its row's escape symbol
+          if (s == max_value) {
+            uint32_t val = get_bits4(x, src);
+            int nbyp = (int)val;
+            while (val == 15u && nbyp < 64) { val = get_bits4(x, src); nbyp += (int)val; }
+            uint32_t raw = 0;
+            for (int t = 0; t < nbyp; ++t) {
+              const uint32_t nib = get_bits4(x, src);
+              if (t < 8) raw |= nib << (t * 4);
+            }
+            value = (int32_t)(raw >> 1);
+            value = (raw & 1u) ? -value - 1 : value + max_value;
+          }
+          src.refill_if_low();  // the escape path may have drained several words
+        }
+        outv[k] = value + (int32_t)m.offset;
+      }
+    };
+    if (nb == SYM_BLK) {
+      decode_block(std::true_type{});
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < SYM_BLK; ++k) {
+          int32_t *a = sp + (size_t)(i0 + k) * ssi;
+          asm volatile("global_store_dword %0, %1, off" ::"v"(a), "v"(outv[k]) : "memory");
+        }
+      }
+    } else {  // the last, ragged block: nothing counts on its stores
+      decode_block(std::false_type{});
+      if (live)
+        for (int k = 0; k < nb; ++k) sp[(size_t)(i0 + k) * ssi] = outv[k];
+    }
+  }
+  if (live && src.over) atomicOr(status, 1);
+}
+
+}  // namespace gc
+}  // namespace licos
+
+using namespace licos;
+using namespace licos::gc;
+
+// ---------------------------------------------------------------------------------------------- host: decoder image
+namespace {
+
+// Mass of a row's 2^k buckets that the best adjacent-symbol pair per bucket does not cover (of 65536), and optionally
+// the records themselves.  c[0 .. len-1], c[len-1] == 65536, symbols 0 .. len-2.
+double row_records(const int32_t *c, int len, int k, uint2 *out) {
+  const int shift = 16 - k, nb = 1 << k, width = 1 << shift;
+  const int last_sym = len - 2;
+  long bad = 0;
+  int f = 0;
+  for (int j = 0; j < nb; ++j) {
+    const int key0 = j << shift, key1 = key0 + width;  // [key0, key1)
+    while (c[f + 1] <= key0) ++f;                       // f: symbol holding key0
+    int l = f;
+    while (c[l + 1] < key1) ++l;                        // l: symbol holding key1 - 1
+    int best = f;
+    long best_cov = -1;
+    for (int s = f; s <= std::max(f, l - 1); ++s) {
+      const int hi = c[std::min(s + 2, len - 1)];
+      const long cov = (long)std::min(hi, key1) - std::max(c[s], key0);
+      if (cov > best_cov) { best_cov = cov; best = s; }
+    }
+    bad += width - best_cov;
+    if (out) {
+      const uint32_t c0 = (uint32_t)c[best], c1 = (uint32_t)c[std::min(best + 1, len - 1)], c2 = (uint32_t)c[std::min(best + 2, len - 1)];
+      out[j] = make_uint2((c0 & 0xFFFFu) | ((c1 - 1u) << 16), ((c2 - 1u) & 0xFFFFu) | ((uint32_t)best << 16));
+    }
+    (void)last_sym;
+  }
+  return (double)bad / 65536.0;
+}
+
+constexpr int K_MIN = 2, K_MAX = 12;
+
+}  // namespace
+
+extern "C" {
+
+int licos_rans_image_build(const int32_t *cdf, const int32_t *cdf_len, const int32_t *offset, int rows, int stride,
+                           const float *row_weight, long budget_bytes, void *out, long *out_bytes) {
+  LICOS_REQUIRE(cdf && cdf_len && offset && out && out_bytes && rows > 0 && rows <= 256 && stride > 1, "rans_image_build: bad arguments");
+  long n_cdf = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int len = cdf_len[r];
+    LICOS_REQUIRE(len >= 3 && len <= stride && len - 2 <= 65535, "rans_image_build: row %d has cdf length %d", r, len);
+    const int32_t *c = cdf + (size_t)r * stride;
+    LICOS_REQUIRE(c[0] == 0 && c[len - 1] == 65536, "rans_image_build: row %d does not span [0, 65536]", r);
+    for (int s = 0; s + 1 < len; ++s) LICOS_REQUIRE(c[s + 1] > c[s], "rans_image_build: row %d symbol %d has no mass", r, s);
+    n_cdf += len - 1;
+  }
+  LICOS_REQUIRE(n_cdf <= 65535, "rans_image_build: %ld cdf entries exceed the 16-bit row bases", n_cdf);
+  auto align16 = [](long v) { return (v + 15) & ~15L; };
+  const long off_meta = align16(sizeof(ImageHeader));
+  const long off_rec = off_meta + align16((long)rows * sizeof(ImageMeta));
+  const long cdf_bytes = align16(n_cdf * 2 + 2);
+  const long rec_budget = (budget_bytes - off_rec - cdf_bytes) / 8;
+  if (rec_budget < (long)rows << K_MIN)
+    return fail(LICOS_EINVAL, "rans_image_build: %ld bytes cannot hold %d rows (%ld cdf entries)", budget_bytes, rows, n_cdf);
+  // greedy over the uncovered mass bad[r][k] of every row at every bucket count: all rows start at 2^K_MIN buckets;
+  // the jump k -> k' (any k' > k: the mass is not monotonic in k) that removes the most weighted mass per added record
+  // goes first, until the budget is spent or nothing is left to gain
+  std::vector<int> k(rows, K_MIN);
+  std::vector<double> bad((size_t)rows * (K_MAX + 1), 0.0);
+  for (int r = 0; r < rows; ++r)
+    for (int kk = K_MIN; kk <= K_MAX; ++kk) bad[(size_t)r * (K_MAX + 1) + kk] = row_records(cdf + (size_t)r * stride, cdf_len[r], kk, nullptr);
+  long used = (long)rows << K_MIN;
+  for (;;) {
+    int pick = -1, pick_k = 0;
+    double best = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      const double w = row_weight ? (double)row_weight[r] : 1.0;
+      const double *br = &bad[(size_t)r * (K_MAX + 1)];
+      for (int kk = k[r] + 1; kk <= K_MAX; ++kk) {
+        const long add = (1L << kk) - (1L << k[r]);
+        if (used + add > rec_budget) break;
+        const double gain = w * (br[k[r]] - br[kk]) / (double)add;
+        if (gain > best) { best = gain; pick = r; pick_k = kk; }
+      }
+    }
+    if (pick < 0) break;
+    used += (1L << pick_k) - (1L << k[pick]);
+    k[pick] = pick_k;
+  }
+  const long off_cdf = off_rec + align16(used * 8);
+  const long total = off_cdf + cdf_bytes;
+  LICOS_REQUIRE(total <= budget_bytes, "rans_image_build: internal size error");
+  unsigned char *blob = static_cast<unsigned char *>(out);
+  std::memset(blob, 0, (size_t)total);
+  ImageHeader h{IMAGE_MAGIC, (uint32_t)rows, (uint32_t)used, (uint32_t)n_cdf, (uint32_t)off_meta, (uint32_t)off_rec, (uint32_t)off_cdf, (uint32_t)total};
+  std::memcpy(blob, &h, sizeof(h));
+  ImageMeta *meta = reinterpret_cast<ImageMeta *>(blob + off_meta);
+  uint2 *rec = reinterpret_cast<uint2 *>(blob + off_rec);
+  uint16_t *c16 = reinterpret_cast<uint16_t *>(blob + off_cdf);
+  long rec_at = 0, cdf_at = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int len = cdf_len[r];
+    const int32_t *c = cdf + (size_t)r * stride;
+    meta[r] = ImageMeta{(uint32_t)rec_at, (uint32_t)(16 - k[r]), (uint32_t)cdf_at | ((uint32_t)(len - 2) << 16), (uint32_t)offset[r]};
+    row_records(c, len, k[r], rec + rec_at);
+    for (int s = 0; s + 1 < len; ++s) c16[cdf_at + s] = (uint16_t)c[s];
+    rec_at += 1L << k[r];
+    cdf_at += len - 1;
+  }
+  *out_bytes = total;
+  return LICOS_OK;
+}
+
+int licos_rans_image_lookup(const void *image, int row, int cf, int32_t *out3) {
+  LICOS_REQUIRE(image && out3, "rans_image_lookup: NULL argument");
+  const unsigned char *blob = static_cast<const unsigned char *>(image);
+  ImageHeader h;
+  std::memcpy(&h, blob, sizeof(h));
+  LICOS_REQUIRE(h.magic == IMAGE_MAGIC && row >= 0 && (uint32_t)row < h.rows && cf >= 0 && cf < 65536, "rans_image_lookup: bad image, row or value");
+  const ImageMeta m = reinterpret_cast<const ImageMeta *>(blob + h.off_meta)[row];
+  int s;
+  uint32_t lo, him;
+  bool fb;
+  image_lookup(m, reinterpret_cast<const uint2 *>(blob + h.off_rec), reinterpret_cast<const uint16_t *>(blob + h.off_cdf), (uint32_t)cf, s, lo, him, fb);
+  out3[0] = s;
+  out3[1] = (int32_t)lo;
+  out3[2] = (int32_t)(him + 1u);
+  return fb ? 1 : 0;
+}
+
+int licos_gc_encode_prepare(const float *y, const float *scales, const float *scale_table, int levels, float scale_bound,
+                            const void *enc_table, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, void *rec,
+                            int32_t *aux, int B, long n, void *stream) {
+  LICOS_REQUIRE(y && scales && scale_table && enc_table && cdf_len && offset && rec && aux, "gc_encode_prepare: NULL buffer");
+  LICOS_REQUIRE(levels > 0 && levels <= 256 && B > 0 && n > 0 && cdf_stride > 1, "gc_encode_prepare: bad sizes");
+  LICOS_REQUIRE((n + 31) / 32 < (1L << 31) && (B + 63) / 64 < 65536, "gc_encode_prepare: too many symbols or streams");
+  hipLaunchKernelGGL(gc_encode_prepare_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((B + 63) / 64)), dim3(256), 0,
+                     as_stream(stream), y, scales, scale_table, levels, scale_bound, static_cast<const uint4 *>(enc_table),
+                     cdf_stride, cdf_len, offset, static_cast<uint4 *>(rec), aux, B, n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint32_t *words, int cap_words, int32_t *nwords,
+                              int32_t *status, int B, void *stream) {
+  LICOS_REQUIRE(rec && aux && words && nwords && status && B > 0 && n > 0 && cap_words >= 2, "rans_encode_records: bad arguments");
+  // four waves per workgroup (one per SIMD, no table to share): 2048 streams occupy 8 CUs instead of 32
+  const int threads = B >= 256 ? 256 : 64 * cdiv(B, 64);
+  hipLaunchKernelGGL(rans_encode_records_kernel, dim3(cdiv(B, threads)), dim3(threads), 0, as_stream(stream),
+                     static_cast<const uint4 *>(rec), aux, n, words, cap_words, nwords, status, B);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16, int B,
+                            long n, void *stream) {
+  LICOS_REQUIRE(scales && scale_table && idx16 && levels > 0 && levels <= 256 && B > 0 && n > 0, "gc_decode_prepare: bad arguments");
+  LICOS_REQUIRE((n + 63) / 64 < (1L << 31) && (B + 63) / 64 < 65536, "gc_decode_prepare: too many symbols or streams");
+  hipLaunchKernelGGL(gc_decode_prepare_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((B + 63) / 64)), dim3(256), 0,
+                     as_stream(stream), scales, scale_table, levels, scale_bound, static_cast<uint4 *>(idx16), B, n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+long licos_rans_image_budget(int waves) {
+  if (waves != 1 && waves != 2) return 0;
+  return 160L * 1024 - 256 - (long)waves * (RING * 64 * 4 + IDEPTH * 64 * 16);
+}
+
+int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off, const void *idx16, long n, const void *image,
+                            const void *image_host_header, int32_t *symbols, long sym_stride_b, long sym_stride_i,
+                            int32_t *status, int B, void *stream) {
+  LICOS_REQUIRE(in && byte_off && idx16 && image && image_host_header && symbols && status && B > 0 && n > 0, "rans_decode_image: bad arguments");
+  LICOS_REQUIRE(((uintptr_t)in & 3) == 0 && ((uintptr_t)image & 15) == 0, "rans_decode_image: misaligned input");
+  ImageHeader h;
+  std::memcpy(&h, image_host_header, sizeof(h));
+  LICOS_REQUIRE(h.magic == IMAGE_MAGIC && h.total_bytes % 16 == 0, "rans_decode_image: not a decoder image");
+  const int waves = B > 64 ? 2 : 1;
+  const size_t fixed = (size_t)waves * (RING * 64 * 4 + IDEPTH * 64 * 16);
+  const size_t lds = fixed + h.total_bytes;
+  LICOS_REQUIRE(lds <= 160 * 1024, "rans_decode_image: image of %u bytes does not fit beside %d waves", h.total_bytes, waves);
+  auto launch = [&](auto kern) -> int {
+    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), lds, as_stream(stream), in, byte_off,
+                       static_cast<const uint4 *>(idx16), n, static_cast<const uint4 *>(image), (int)h.total_bytes,
+                       (int)h.off_meta, (int)h.off_rec, (int)h.off_cdf, symbols, sym_stride_b, sym_stride_i, status, B);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  };
+  return waves == 2 ? launch(rans_decode_image_kernel<2>) : launch(rans_decode_image_kernel<1>);
+}
+
+}  // extern "C"

@@ -438,6 +438,20 @@ class GaussianConditional(nn.Module):
 
     coder_tables = EntropyBottleneck.coder_tables
     coder_tables_host = EntropyBottleneck.coder_tables_host
+
+    def coder_image(self):
+        """(device blob, host blob) of the decoder image the scale-conditioned fast path keeps in LDS
+        (licos_rans_image_build; rebuilt with the coder tables), or None when the tables do not fit one."""
+        tables = self.coder_tables()
+        if getattr(self, "_image_for", None) is not tables:  # (the tuple is rebuilt whenever the tables are)
+            cdf_h, len_h, off_h, _ = self._coder_host
+            try:
+                blob = ops.rans_image_build(cdf_h, len_h, off_h) if cdf_h.shape[0] <= 256 else None
+            except ValueError:
+                blob = None
+            self._image = None if blob is None else (torch.from_numpy(blob).to(self._quantized_cdf.device), blob)
+            self._image_for = tables
+        return self._image
     _check_cdfs = EntropyBottleneck._check_cdfs
     _compress_host = EntropyBottleneck._compress_host
     _decompress_host = EntropyBottleneck._decompress_host

@@ -202,6 +202,7 @@ class ScaleHyperprior(CompressionModel):
         self.N = int(N)
         self.M = int(M)
         self.precision = precision
+        self.chunk = 512  # tiles per pipeline chunk of the large-batch codec (licos_amd/codec.py)
 
     @property
     def downsampling_factor(self):
@@ -223,6 +224,9 @@ class ScaleHyperprior(CompressionModel):
 
     def compress(self, x):
         self._sync_precision()
+        from . import codec
+        if x.shape[0] and codec.hyper_fast_path(self, x.shape[0]):
+            return codec.compress_hyper(self, x, chunk=self.chunk)
         y = self.g_a(x)
         z = self.h_a(y)
         z_strings = self.entropy_bottleneck.compress(z)
@@ -235,6 +239,9 @@ class ScaleHyperprior(CompressionModel):
     def decompress(self, strings, shape):
         assert isinstance(strings, list) and len(strings) == 2
         self._sync_precision()
+        from . import codec
+        if len(strings[0]) and codec.hyper_fast_path(self, len(strings[0])):
+            return codec.decompress_hyper(self, strings, shape, chunk=self.chunk)
         z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
         scales_hat = self.h_s(z_hat)
         indexes = self.gaussian_conditional.build_indexes_interleaved(scales_hat)

@@ -532,6 +532,86 @@ def rans_decode_batch(data, byte_off, sym_stride_b, sym_stride_i, n, plane, cdf,
     return status
 
 
+def rans_image_budget(waves=2):
+    """Bytes of LDS a decoder image may take beside the decode kernel's rings (licos_rans_decode_image)."""
+    return int(_lib.load().licos_rans_image_budget(int(waves)))
+
+
+def rans_image_build(cdf, cdf_len, offset, budget_bytes=None, row_weight=None):
+    """Decoder image (numpy uint8 blob) of an integer CDF table: per-row bucket records + 16-bit symbol starts
+    (licos_amd/csrc/rans_image.hpp).  Host-side, once per table."""
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    budget = rans_image_budget(2) if budget_bytes is None else int(budget_bytes)
+    out = np.zeros(budget, dtype=np.uint8)
+    used = ctypes.c_long(0)
+    wp = ctypes.c_void_p(0)
+    if row_weight is not None:
+        w = np.ascontiguousarray(row_weight, dtype=np.float32)
+        wp = ctypes.c_void_p(w.ctypes.data)
+    rc = _lib.load().licos_rans_image_build(cp, lp, op, cdf_a.shape[0], cdf_a.shape[1], wp, budget,
+                                            ctypes.c_void_p(out.ctypes.data), ctypes.addressof(used))
+    _lib.check(rc, "rans_image_build")
+    return out[: used.value].copy()
+
+
+def rans_image_lookup(image, row, cf):
+    """(symbol, lo, hi, slow_path) of value cf in `row` through the image - the decode kernel's own search, on the host."""
+    out = (ctypes.c_int32 * 3)()
+    rc = _lib.load().licos_rans_image_lookup(ctypes.c_void_p(image.ctypes.data), int(row), int(cf), ctypes.addressof(out))
+    _lib.check(rc, "rans_image_lookup")
+    return out[0], out[1], out[2], bool(rc)
+
+
+def gc_encode_prepare(y, scales, scale_table, scale_bound, enc_table, cdf_len, offset, cdf_stride):
+    """(rec [n][B] 16-byte records as int32 [n][B][4], aux int32 [n][B]) for licos_rans_encode_records."""
+    _dev(y, scales, scale_table, enc_table, cdf_len, offset)
+    b = y.shape[0]
+    n = y[0].numel()
+    rec = torch.empty((n, b, 4), device=y.device, dtype=torch.int32)
+    aux = torch.empty((n, b), device=y.device, dtype=torch.int32)
+    rc = _lib.load().licos_gc_encode_prepare(_p(_f32(y)), _p(_f32(scales)), _p(_f32(scale_table)), scale_table.numel(), scale_bound,
+                                             _p(enc_table), cdf_stride, _p(cdf_len), _p(offset), _p(rec), _p(aux), b, n, _stream())
+    _lib.check(rc, "gc_encode_prepare")
+    return rec, aux
+
+
+def rans_encode_records(rec, aux, cap_words):
+    """The serial encoder over prepared records: (words [cap_words][B], nwords [B], status [1])."""
+    _dev(rec, aux)
+    n, b = aux.shape
+    words = torch.empty((cap_words, b), device=aux.device, dtype=torch.int32)
+    nwords = torch.empty(b, device=aux.device, dtype=torch.int32)
+    status = torch.zeros(1, device=aux.device, dtype=torch.int32)
+    rc = _lib.load().licos_rans_encode_records(_p(rec), _p(aux), n, _p(words), cap_words, _p(nwords), _p(status), b, _stream())
+    _lib.check(rc, "rans_encode_records")
+    return words, nwords, status
+
+
+def gc_decode_prepare(scales, scale_table, scale_bound):
+    """Row byte per symbol in the decoder's granule layout: uint8 [ceil(n/16)][B][16]."""
+    _dev(scales, scale_table)
+    b = scales.shape[0]
+    n = scales[0].numel()
+    idx16 = torch.empty(((n + 15) // 16, b, 16), device=scales.device, dtype=torch.uint8)
+    rc = _lib.load().licos_gc_decode_prepare(_p(_f32(scales)), _p(_f32(scale_table)), scale_table.numel(), scale_bound, _p(idx16), b, n,
+                                             _stream())
+    _lib.check(rc, "gc_decode_prepare")
+    return idx16
+
+
+def rans_decode_image(data, byte_off, idx16, n, image_dev, image_host, symbols, sym_stride_b, sym_stride_i, batch, status=None,
+                      sym_offset=0):
+    _dev(data, byte_off, idx16, image_dev, symbols)
+    if status is None:
+        status = torch.zeros(1, device=data.device, dtype=torch.int32)
+    rc = _lib.load().licos_rans_decode_image(_p(data), _p(byte_off), _p(idx16), n, _p(image_dev), ctypes.c_void_p(image_host.ctypes.data),
+                                             _p_off(symbols, sym_offset), sym_stride_b, sym_stride_i, _p(status), batch, _stream())
+    _lib.check(rc, "rans_decode_image")
+    return status
+
+
 def host_threads():
     """Worker threads for the host coder: this process's share of the box's cores (a GPU box gives one GPU 16)."""
     try:

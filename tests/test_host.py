@@ -280,3 +280,41 @@ def test_bench_flop_accounting_matches_the_survey():
     assert bench.stage_flops("deconv", 128, 128, 64, 64, norm=True) - bench.stage_flops("deconv", 128, 128, 64, 64) == 2.0 * 128 * 128 * 128 * 128
     # the first stage as the kernel runs it (3 x 3 stride 1 over the space-to-depth image) is the same work
     assert bench.stage_flops("conv", 3, 128, 256, 256) == 2.0 * 128 * 128 * 25 * 3 * 128
+
+
+def test_decoder_image_is_exact_on_every_value():
+    """Host-side check of the image the kernel searches (the same inline function, licos_rans_image_lookup): every row,
+    a dense sweep of 16-bit values, under the default budget and a starved one."""
+    sd = {}
+    om.gc_update(sd)
+    cdf, cdf_len, offset = (sd["gaussian_conditional." + k].numpy() for k in ("_quantized_cdf", "_cdf_length", "_offset"))
+    for budget in (None, 64 * 1024):
+        img = ops.rans_image_build(cdf, cdf_len, offset, budget_bytes=budget)
+        slow = 0
+        for r in range(cdf.shape[0]):
+            row = cdf[r, : cdf_len[r]]
+            cfs = np.unique(np.concatenate((np.arange(0, 65536, 97), row[:-1], np.maximum(row[1:] - 1, 0))))
+            want = np.searchsorted(row, cfs, side="right") - 1
+            for cf, s in zip(cfs.tolist(), want.tolist()):
+                got = ops.rans_image_lookup(img, r, cf)
+                assert got[:3] == (s, int(row[s]), int(row[s + 1])), (budget, r, cf, got)
+                slow += got[3]
+        assert slow > 0  # the bounded search is exercised too
+
+
+def test_bench_spawner_stops_all_ranks_when_one_fails():
+    """`bench.py --gpus 2` from a plain shell starts its own ranks.  Here (no GPU) every rank fails at start-up: the parent
+    must notice, end the group and exit non-zero promptly, with the failing rank's stderr relayed - not wait on rank 0."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "8",
+                        "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True,
+                       timeout=300)
+    assert p.returncode != 0
+    assert time.monotonic() - t0 < 240
+    assert b"exited with status" in p.stderr and b"stderr (tail)" in p.stderr

@@ -262,7 +262,9 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/
  *
  * licos_gc_encode_prepare: y, scales [B][n] fp32 (NCHW order) -> rec [n][B] 16-byte records, aux [n][B] int32 (raw
  * escape values).  scale_table: the `levels` sorted scales of build_indexes(); enc_table: licos_rans_build_enc_table's
- * output on the device.  licos_rans_encode_records: the serial part; words / nwords / status as licos_rans_encode_batch.
+ * output on the device.  licos_rans_encode_records: the serial part; `words` holds (cap_words + 1) rows of B words - row 0
+ * is a dump row, stream b's nwords[b] words end up in rows cap_words + 1 - nwords[b] .. cap_words (pass words + B to
+ * licos_rans_compact); nwords / status as licos_rans_encode_batch (status is also set when a stream fills its rows exactly).
  *
  * licos_rans_image_build (host): turns the integer CDF table into the decoder image (meta, bucket records, 16-bit
  * symbol starts; licos_amd/csrc/rans_image.hpp) of at most budget_bytes (licos_rans_image_budget(waves) = what fits

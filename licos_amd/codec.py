@@ -1,4 +1,5 @@
-"""Chunk-pipelined encode / decode of a tile batch for the 16-bit path.
+"""Chunk-pipelined encode / decode of a tile batch, either precision (fp16 MFMA transforms, or the fp32 parity path's
+three-pass split-operand transforms: the same pipeline, with fp32 NCHW activations bounded per chunk).
 
 The rANS recurrence is sequential inside a stream, so a coder launch is latency-bound: one lane per
 tile, a few waves in total, a fixed ~N_symbols x chain-latency no matter how many tiles ride along.
@@ -15,6 +16,7 @@ import torch
 from . import engine, ops
 
 _streams = {}
+CODER_STREAMS = 8  # side streams the hyperprior codec spreads its chunks' coder launches over
 
 # Optional host-side section timing (tools/profile_step.py): when a dict, every section boundary
 # synchronises the device and accumulates wall-clock seconds.  None in production.
@@ -83,7 +85,8 @@ def _chunks(total, size):
     return [(s, min(size, total - s)) for s in range(0, total, size)]
 
 
-def compress_fp16(net, x, chunk=1024, cap_words=None):
+def compress_chunked(net, x, chunk=1024, cap_words=None):
+    """FactorizedPrior.compress for any batch size and either precision (`net.g_a` dispatches on it)."""
     eb = net.entropy_bottleneck
     cdf, cdf_len, offset, table = eb.coder_tables()
     if x.dtype != torch.float32 or x.dim() != 4:
@@ -151,14 +154,14 @@ def compress_fp16(net, x, chunk=1024, cap_words=None):
         if cap_words >= 2 * nsym + 8:
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del queued
-        return compress_fp16(net, x, chunk=chunk, cap_words=2 * nsym + 8)
+        return compress_chunked(net, x, chunk=chunk, cap_words=2 * nsym + 8)
     main.wait_stream(side)
     main.wait_stream(copy)
     sec.mark("c.drain (lengths, compact, D2H, bytes)")
     return {"strings": [PackedStrings(strings, segments)], "shape": torch.Size(shape)}
 
 
-def decompress_fp16(net, strings, shape, chunk=1024):
+def decompress_chunked(net, strings, shape, chunk=1024):
     eb = net.entropy_bottleneck
     cdf, cdf_len, offset, _ = eb.coder_tables()
     assert isinstance(strings, list) and len(strings) == 1
@@ -207,16 +210,24 @@ def decompress_fp16(net, strings, shape, chunk=1024):
         keep.append((data, byte_off))
         events.append(ev)
     sec.mark("d.queue H2D+decode")
+    fp16 = net.precision == "fp16"
     for (s0, n, _, _), ev in zip(pieces, events):
         main.wait_event(ev)
-        y_blk = torch.zeros((n, (C + 15) // 16, h, w, 16), device=dev, dtype=torch.float16) if C % 16 else \
-            torch.empty((n, C // 16, h, w, 16), device=dev, dtype=torch.float16)
-        ops.eb_dequantize(sym, 1, B, med, n, C, h, w, want_nchw=False, blk16=y_blk, sym_offset=s0)
-        engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+        if fp16:
+            y_blk = torch.zeros((n, (C + 15) // 16, h, w, 16), device=dev, dtype=torch.float16) if C % 16 else \
+                torch.empty((n, C // 16, h, w, 16), device=dev, dtype=torch.float16)
+            ops.eb_dequantize(sym, 1, B, med, n, C, h, w, want_nchw=False, blk16=y_blk, sym_offset=s0)
+            engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+        else:  # the parity path: fp32 NCHW latents, y_hat = symbol + median exactly as the reference's decompress
+            y_hat = ops.eb_dequantize(sym, 1, B, med, n, C, h, w, sym_offset=s0)
+            x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
     sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
     return {"x_hat": x_hat}
+
+
+compress_fp16, decompress_fp16 = compress_chunked, decompress_chunked  # (names of the first two rounds)
 
 
 # ------------------------------------------------------------------------------------------------ scale hyperprior
@@ -268,11 +279,14 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     B = x.shape[0]
     dev = x.device
     main = torch.cuda.current_stream(dev)
-    side, copy = _stream(dev, "coder"), _stream(dev, "copy")
+    copy = _stream(dev, "copy")
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
     queued, shape = [], None
-    for (s0, n) in _chunks(B, chunk):
+    for ci, (s0, n) in enumerate(_chunks(B, chunk)):
+        # a coder launch is a latency chain on a handful of CUs: the chunks' launches run side by side, each on a
+        # stream of its own (on ONE stream they would queue up behind each other, ~50 ms apiece)
+        side = _stream(dev, "coder%d" % (ci % CODER_STREAMS))
         y = net.g_a(x[s0:s0 + n])
         z = net.h_a(y)
         if shape is None:
@@ -315,7 +329,8 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del queued
         return compress_hyper(net, x, chunk=chunk, cap_words=2 * ny + 8)
-    main.wait_stream(side)
+    for ci in range(min(CODER_STREAMS, len(segments))):
+        main.wait_stream(_stream(dev, "coder%d" % ci))
     main.wait_stream(copy)
     ysegs = [(s0, n, t, yo) for (s0, n, t, yo, _) in segments]
     zsegs = [(s0, n, t, zo) for (s0, n, t, _, zo) in segments]
@@ -356,7 +371,6 @@ def decompress_hyper(net, strings, shape, chunk=512):
     nz, zplane = N * h * w, h * w
     ny = M * (4 * h) * (4 * w)
     main = torch.cuda.current_stream(dev)
-    side = _stream(dev, "coder")
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
     pieces = [(s0, n) for (s0, n) in _chunks(B, chunk)]
@@ -365,10 +379,19 @@ def decompress_hyper(net, strings, shape, chunk=512):
         pieces = [(s0, n) for (s0, n, _, _) in ystrs.segments]
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     zsym = torch.empty((nz, B), device=dev, dtype=torch.int32)
+    # z: every tile's string in ONE launch (2 ms whatever the batch; a launch per piece would queue them up on this stream)
     zup = _upload(zstrs, pieces, dev)
-    for (s0, n), (data, off) in zip(pieces, zup):
-        _timed_coder("z_decode", lambda: ops.rans_decode_batch(data, off, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, n, sym_offset=s0,
-                                                               status=status, off_offset=0))
+    if len(zup) > 1:  # (every string is a whole number of 32-bit words: the pieces concatenate without padding)
+        zdata = torch.cat([data for (data, _) in zup])
+        base, offs = 0, []
+        for (data, off) in zup:
+            offs.append(off[:-1] + base)
+            base += data.numel()
+        zoff_all = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
+    else:
+        zdata, zoff_all = zup[0]
+    _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
+                                                           status=status, off_offset=0))
     z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
     yup = _upload(ystrs, pieces, dev)
     fp16 = net.precision == "fp16"
@@ -377,7 +400,8 @@ def decompress_hyper(net, strings, shape, chunk=512):
     x_hat = torch.empty((B, cout, 64 * h, 64 * w), device=dev, dtype=torch.float32)
     zeros = torch.zeros(M, device=dev, dtype=torch.float32)
     events, keep = [], []
-    for (s0, n), (data, off) in zip(pieces, yup):
+    for ci, ((s0, n), (data, off)) in enumerate(zip(pieces, yup)):
+        side = _stream(dev, "coder%d" % (ci % CODER_STREAMS))
         scales = net.h_s(z_hat[s0:s0 + n])
         idx16 = ops.gc_decode_prepare(scales.contiguous(), gc.scale_table, bound)
         sym = torch.empty((ny, n), device=dev, dtype=torch.int32)
@@ -400,7 +424,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
             engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
         else:
             y_hat = ops.eb_dequantize(sym, 1, n, zeros, n, M, 4 * h, 4 * w)
-            x_hat[s0:s0 + n] = net.g_s(y_hat).clamp_(0, 1)
+            x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
     if int(status.item()) != 0:  # synchronises; also keeps the side stream's tensors alive until it is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
     return {"x_hat": x_hat}

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
         if (!FULL && k >= nb) break;
         const int32_t value = sv[k] - off;
         const bool escape = value < 0 || value >= max_value;
-        if (__any(escape)) {  // uniform and rare: some stream codes an out-of-range value
+        if (__builtin_expect(__any(escape), 0)) {  // uniform and rare: some stream codes an out-of-range value
           if (escape) {
             const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
             int nbyp = 0;
@@ -266,7 +266,7 @@ struct RingSource {
   int nw, rd, filled, last;
   bool over;
   // `fallback`: any readable device word, addressed instead of the stream when the stream is empty
-  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
+  __device__ __forceinline__ void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
     p = n > 0 ? ptr : fallback; nw = n; last = n > 0 ? n - 1 : 0; ring = lane_ring; rd = 0; over = false; filled = 0;
     top_up();
     top_up();
@@ -275,7 +275,7 @@ struct RingSource {
   // issued as asm with their own wait: loads the compiler knows about make it put a conservative s_waitcnt vmcnt(0)
   // into every iteration of the symbol loop (the refill is a rarely taken branch of it), and that wait also waits
   // for the symbol stores of the last flush - a memory round trip per SYM_BUF symbols on the serial chain.
-  __device__ inline void top_up() {
+  __device__ __forceinline__ void top_up() {
     uint32_t w[16];
     const bool room = filled - rd <= RING - 16;
 #pragma unroll
@@ -293,19 +293,19 @@ struct RingSource {
       filled += 16;
     }
   }
-  __device__ inline void refill_if_low() {
-    if (__any(filled - rd <= RING_LOW)) top_up();
+  __device__ __forceinline__ void refill_if_low() {
+    if (__builtin_expect(__any(filled - rd <= RING_LOW), 0)) top_up();
   }
   // branch-free pair for the common renormalisation: peek() the next word early, advance(true) if it was used.
   // The ring read carries no guard (a guarded read becomes a branch with its own s_waitcnt, which serialises this LDS
   // round trip with the table lookup's): words past the end of the stream are stored as zeros by top_up(), and the ring
   // checks keep rd < filled (a block of SYM_BUF symbols consumes at most SYM_BUF <= RING_LOW words between checks).
-  __device__ inline uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
-  __device__ inline void advance(bool used) {
+  __device__ __forceinline__ uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
+  __device__ __forceinline__ void advance(bool used) {
     over = over || (used && rd >= nw);
     rd += used ? 1 : 0;
   }
-  __device__ inline uint32_t next() {
+  __device__ __forceinline__ uint32_t next() {
     if (rd >= nw) over = true;
     const uint32_t w = ring[(rd & (RING - 1)) * 64];
     ++rd;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void rans_decode_plane_kernel(const uint8_t *_
         uint32_t lo = adv ? c1m + 1u : (rec.x & 0xFFFFu);
         uint32_t him = adv ? c2m : c1m;  // cdf[s + 1] - 1 of the symbol taken
         int s = (int)(rec.y >> 16) + (adv ? 1 : 0);
-        if (__any(cf > c2m)) {  // uniform, per-lane walk: some stream sits in a bucket that holds three or more symbols
+        if (__builtin_expect(__any(cf > c2m), 0)) {  // uniform, per-lane walk: some stream sits in a bucket that holds three or more symbols
           if (cf > c2m) {
             s = (int)(rec.y >> 16) + 2;
             if (s > len - 2) s = len - 2;  // (malformed tables only)
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void rans_decode_plane_kernel(const uint8_t *_
         x = need ? ((x << 32) | w_next) : x;
         src.advance(need);
         int32_t value = s;
-        if (__any(value == max_value)) {  // uniform and rare: some stream hit the escape symbol
+        if (__builtin_expect(__any(value == max_value), 0)) {  // uniform and rare: some stream hit the escape symbol
           if (value == max_value) {
             uint32_t val = get_bits4p(x, src);
             int nbyp = (int)val;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) void rans_encode_indexed_kernel(const int32_t *
       if (!FULL && k >= nb) break;
       const int32_t value = sv[k];
       const bool escape = value < 0 || value >= mx[k];
-      if (__any(escape)) {  // uniform and rare
+      if (__builtin_expect(__any(escape), 0)) {  // uniform and rare
         if (escape) {
           const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - mx[k]));
           int nbyp = 0;

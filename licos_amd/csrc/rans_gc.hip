@@ -27,7 +27,12 @@ namespace gc {
 
 constexpr uint64_t RANS_L = 1ull << 31;
 constexpr int SYM_BLK = 16;          // symbols per decode block (= one 16-byte row-index granule per stream)
-constexpr int RING = 32, RING_LOW = 16;  // LDS ring of stream words per lane; a block takes at most SYM_BLK off it between checks
+// LDS ring of stream words per lane.  A refill tops up every lane that has room for 16 more words (level <= RING - 16), and
+// is triggered when ANY lane is down to RING_LOW: the gap between the two is what makes a refill lift the whole wave well
+// above the trigger - with RING = 32 the two coincided, only the triggering lanes were topped up, and some lane of the 64
+// triggered a full memory round trip nearly every block (93 of 600 cycles per symbol, in-kernel stamps).  A block takes at
+// most SYM_BLK words off the ring between checks.
+constexpr int RING = 64, RING_LOW = 24;
 constexpr int IDEPTH = 4;            // LDS-DMA slots of row-index granules per wave
 constexpr uint32_t REC_ESCAPE = 0x80000000u;  // flag in EncRec's (freq | shift << 16) dword: raw value in the aux plane
 
@@ -69,7 +74,9 @@ __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__r
         if (v < 0) { raw = -2 * v - 1; v = max_value; esc = true; }
         else if (v >= max_value) { raw = 2 * (v - max_value); v = max_value; esc = true; }
         e = enc_table[(size_t)c * cdf_stride + v];
-        if (esc) e.w |= REC_ESCAPE;
+        // the serial kernel's form of the last dword: 2^16 - freq (what the update multiplies by, and what the
+        // renormalisation bound is computed from) | shift << 16 | escape flag
+        e.w = ((0x10000u - (e.w & 0xFFFFu)) & 0xFFFFu) | (e.w & 0x7FFF0000u) | (esc ? REC_ESCAPE : 0u);
       }
       t_rec[p][r] = e;
       t_aux[p][r] = raw;
@@ -90,21 +97,35 @@ __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------- encode: serial part
+// 16 B per lane, global -> LDS, no register round trip (LDS address = wave base + lane * 16); counted in vmcnt only.
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(m0v)
+               : "memory");
+}
+
+// Output words of a stream, back to front, in the interleaved scratch [row][stream]: rows 1 .. cap hold the words (the
+// first word written goes to row cap), row 0 is a dump row - once a stream has used all its rows, further words land
+// there and the stream is flagged - so the bookkeeping of a word is one select, one subtract and one max on a 32-bit
+// byte offset.  Every store is issued from here as inline assembly (scalar base + vector offset): the kernel's waits
+// count vector-memory operations (see below) and must know each one.
 struct WordSink {
-  uint32_t *words;
-  int B, b, wp;
-  bool overflow;
-  __device__ inline void put(uint32_t w) {
-    if (wp > 0) { --wp; words[(size_t)wp * B + b] = w; }
-    else overflow = true;
+  const uint32_t *base;  // row 0 of this stream (wave-uniform part folded in by the compiler or not - a 64-bit pair either way)
+  uint32_t off;          // byte offset of the next free row; 0 = the dump row
+  uint32_t stride;       // bytes between two rows
+  __device__ inline void store(uint32_t w) const {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(w), "s"(base) : "memory");
   }
-  // branch-free: the word is always stored to the next free slot, the slot is claimed only when `emit` is set
-  __device__ inline void put_if(bool emit, uint32_t w) {
-    const int slot = wp > 0 ? wp - 1 : 0;
-    words[(size_t)slot * B + b] = w;
-    overflow = overflow || (emit && wp <= 0);
-    wp = emit ? slot : wp;
+  __device__ inline void claim(bool emit) {
+    const uint32_t dec = emit ? stride : 0u;
+    off = off >= dec ? off - dec : 0u;
   }
+  // branch-free: the word is always stored to the next free row, the row is claimed only when `emit` is set
+  __device__ inline void put_if(bool emit, uint32_t w) { store(w); claim(emit); }
+  __device__ inline void put(uint32_t w) { put_if(true, w); }
 };
 
 __device__ inline void put_bits4(uint64_t &x, WordSink &sink, uint32_t val) {
@@ -112,66 +133,109 @@ __device__ inline void put_bits4(uint64_t &x, WordSink &sink, uint32_t val) {
   x = (x << 4) | val;
 }
 
-constexpr int ENC_BATCH = 8;
+constexpr int ENC_BATCH = 8, ENC_DEPTH = 8, ENC_AHEAD = 4;  // records are requested ENC_AHEAD batches (32 symbols, ~6 us) ahead
 
-__global__ __launch_bounds__(256) void rans_encode_records_kernel(const uint4 *__restrict__ rec, const int32_t *__restrict__ aux,
-                                                                 long n, uint32_t *__restrict__ words, int cap_words,
-                                                                 int32_t *__restrict__ nwords, int32_t *__restrict__ status,
-                                                                 int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;  // no barrier below
-  WordSink sink{words, B, b, cap_words, false};
-  uint64_t x = RANS_L;
+// Records arrive by LDS-DMA ENC_AHEAD batches ahead; words leave by stores nobody waits for.  vmcnt discipline of batch t:
+//     wait for batch t's records | read them | request batch t + ENC_AHEAD | ENC_BATCH symbols, one store each (+ escapes)
+// Everything issued after batch t's request may stay in flight: `s_waitcnt vmcnt(N)` with N = the number of those
+// operations (each batch issues ENC_BATCH request pieces and at least ENC_BATCH stores) waits for that request alone.
+// (The first version fetched records into registers and let the compiler place the waits: `vmcnt(0)` at every batch,
+// i.e. a full round trip of the stores just issued per 8 symbols - 235 ns per symbol, most of it that wait.)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rans_encode_records_kernel(const uint4 *__restrict__ rec, const int32_t *__restrict__ aux,
+                                                                         long n, uint32_t *__restrict__ words, int cap_words,
+                                                                         int32_t *__restrict__ nwords, int32_t *__restrict__ status,
+                                                                         int B) {
+  extern __shared__ __attribute__((aligned(16))) uint4 s_recs[];  // [WAVES][ENC_DEPTH][ENC_BATCH][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_b0 = (blockIdx.x * WAVES + wave) * 64;
+  if (wave_b0 >= B) return;  // no barrier below
+  const bool live = wave_b0 + lane < B;
+  const int b = live ? wave_b0 + lane : B - 1;  // idle lanes shadow the last stream; their stores are masked off below
+  uint4 *ring = s_recs + wave * (ENC_DEPTH * ENC_BATCH * 64);
   const uint4 *rp = rec + b;
   const int32_t *ap = aux + b;
-  uint4 nxt[ENC_BATCH];
-  auto fetch = [&](long i1) {
+  const long nbat = (n + ENC_BATCH - 1) / ENC_BATCH;
+  auto request = [&](long t) {
 #pragma unroll
     for (int k = 0; k < ENC_BATCH; ++k) {
-      const long i = i1 - 1 - k;
-      nxt[k] = (i >= 0) ? rp[(size_t)i * B] : make_uint4(0, 0, 0, 0);
+      long i = n - 1 - t * ENC_BATCH - k;
+      i = i < 0 ? 0 : i;  // past the front of the stream (last batch only): a harmless re-read, never coded
+      dma16(rp + (size_t)i * B, ring + ((t & (ENC_DEPTH - 1)) * ENC_BATCH + k) * 64);
     }
   };
-  auto code = [&](auto full_c, long i1, int nb, bool more) {
-    constexpr bool FULL = decltype(full_c)::value;
+  // (the scratch of a launch stays below 4 GB: checked by the launcher)
+  WordSink sink{words, ((uint32_t)cap_words * (uint32_t)B + (uint32_t)b) * 4u, (uint32_t)B * 4u};
+  uint64_t x = RANS_L;
+  for (int t = 0; t < ENC_AHEAD; ++t)
+    if (t < nbat) request(t);
+  for (long t = 0; t < nbat; ++t) {
+    // operations issued after batch t's request: the stores of min(t, ENC_AHEAD) batches and the requests of the batches
+    // up to t + ENC_AHEAD - 1 that exist - ENC_BATCH apiece (escapes only add stores): all of them may stay in flight
+    {
+      const long later = (t < ENC_AHEAD ? t : ENC_AHEAD) + (nbat - 1 - t < ENC_AHEAD - 1 ? nbat - 1 - t : ENC_AHEAD - 1);
+      static_assert(ENC_BATCH == 8 && ENC_AHEAD == 4, "the counted waits below are written for 8 operations per batch, up to 7 batches");
+      switch (later) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+      }
+    }
     uint4 cur[ENC_BATCH];
 #pragma unroll
-    for (int k = 0; k < ENC_BATCH; ++k) cur[k] = nxt[k];
-    if (more) fetch(i1 - ENC_BATCH);  // the next batch's records: their latency hides under this batch's chain
+    for (int k = 0; k < ENC_BATCH; ++k) cur[k] = ring[((t & (ENC_DEPTH - 1)) * ENC_BATCH + k) * 64 + lane];
+    if (t + ENC_AHEAD < nbat) request(t + ENC_AHEAD);
+    const long i1 = n - t * ENC_BATCH;  // symbols i1 - 1 ... i1 - ENC_BATCH
+    auto code_batch = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int k = 0; k < ENC_BATCH; ++k) {
-      if (!FULL && k >= nb) break;
-      const bool escape = (cur[k].w & REC_ESCAPE) != 0;
-      if (__any(escape)) {  // uniform and rare: some stream codes a value outside its row's range
-        if (escape) {
-          const uint32_t raw = (uint32_t)ap[(size_t)(i1 - 1 - k) * B];
-          int nbyp = 0;
-          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-          // coding order is [symbol, count nibble, raw nibbles low -> high]; emitted reversed
-          for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
-          put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+      for (int k = 0; k < ENC_BATCH; ++k) {
+        if (!FULL && i1 - 1 - k < 0) break;
+        const bool escape = (cur[k].w & REC_ESCAPE) != 0;
+#if defined(LICOS_ABL) && LICOS_ABL == 12
+        if (false) {
+#else
+        if (__builtin_expect(__any(escape), 0)) {  // uniform and rare: some stream codes a value outside its row's range
+#endif
+          if (escape) {
+            const uint32_t raw = (uint32_t)ap[(size_t)(i1 - 1 - k) * B];
+            int nbyp = 0;
+            while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+            // coding order is [symbol, count nibble, raw nibbles low -> high]; emitted reversed
+            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+          }
         }
+        const uint32_t cfreq = cur[k].w & 0xFFFFu;  // 2^16 - freq
+        const uint32_t shift = (cur[k].w >> 16) & 0x7FFFu;
+        const uint64_t rcp = ((uint64_t)cur[k].y << 32) | cur[k].x;
+        // x >= freq << 47  <=>  hi(x) >= (2^16 - cfreq) << 15  <=>  hi(x) + (cfreq << 15) >= 2^31   (hi(x) < 2^31)
+        const bool emit = (uint32_t)(x >> 32) + (cfreq << 15) >= 0x80000000u;
+        sink.put_if(emit, (uint32_t)x);
+        x = emit ? (x >> 32) : x;
+        const uint64_t q = __umul64hi(x, rcp) >> shift;
+        x = x + cur[k].z + q * (uint64_t)cfreq;
       }
-      const uint32_t f16 = cur[k].w & 0xFFFFu;
-      const uint32_t freq = f16 ? f16 : 65536u;
-      const uint32_t shift = (cur[k].w >> 16) & 0x7FFFu;
-      const uint64_t rcp = ((uint64_t)cur[k].y << 32) | cur[k].x;
-      // x >= freq << 47 compares the high words (the bound's low 47 bits are 0)
-      const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
-      sink.put_if(emit, (uint32_t)x);
-      x = emit ? (x >> 32) : x;
-      const uint64_t q = __umul64hi(x, rcp) >> shift;
-      x = x + cur[k].z + q * (uint64_t)(65536u - freq);
+    };
+    if (live) {
+      if (__builtin_expect(i1 >= ENC_BATCH, 1)) code_batch(std::true_type{});
+      else code_batch(std::false_type{});
     }
-  };
-  fetch(n);
-  long i1 = n;
-  for (; i1 >= ENC_BATCH; i1 -= ENC_BATCH) code(std::true_type{}, i1, ENC_BATCH, i1 - ENC_BATCH > 0);
-  if (i1 > 0) code(std::false_type{}, i1, (int)i1, false);
-  sink.put((uint32_t)(x >> 32));
-  sink.put((uint32_t)x);
-  nwords[b] = cap_words - sink.wp;
-  if (sink.overflow) atomicOr(status, 1);
+  }
+  if (live) {
+    sink.put((uint32_t)(x >> 32));
+    sink.put((uint32_t)x);
+    // rows used = cap - (next free row); a stream that reached the dump row is reported as overflowed (it may have
+    // fitted exactly: the caller's retry with the worst-case capacity settles that)
+    const uint32_t row = sink.off / sink.stride;
+    nwords[b] = cap_words - (int)row;
+    if (row == 0) atomicOr(status, 1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- decode: prepare
@@ -207,12 +271,12 @@ struct RingSource {
   uint32_t *ring;
   int nw, rd, filled, last;
   bool over;
-  __device__ inline void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
+  __device__ __forceinline__ void init(const uint32_t *ptr, int n, uint32_t *lane_ring, const uint32_t *fallback) {
     p = n > 0 ? ptr : fallback; nw = n; last = n > 0 ? n - 1 : 0; ring = lane_ring; rd = 0; over = false; filled = 0;
     top_up();
     top_up();
   }
-  __device__ inline void top_up() {
+  __device__ __forceinline__ void top_up() {
     uint32_t w[16];
     const bool room = filled - rd <= RING - 16;
 #pragma unroll
@@ -230,15 +294,15 @@ struct RingSource {
       filled += 16;
     }
   }
-  __device__ inline void refill_if_low() {
-    if (__any(filled - rd <= RING_LOW)) top_up();
+  __device__ __forceinline__ void refill_if_low() {
+    if (__builtin_expect(__any(filled - rd <= RING_LOW), 0)) top_up();
   }
-  __device__ inline uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
-  __device__ inline void advance(bool used) {
+  __device__ __forceinline__ uint32_t peek() const { return ring[(rd & (RING - 1)) * 64]; }
+  __device__ __forceinline__ void advance(bool used) {
     over = over || (used && rd >= nw);
     rd += used ? 1 : 0;
   }
-  __device__ inline uint32_t next() {
+  __device__ __forceinline__ uint32_t next() {
     if (rd >= nw) over = true;
     const uint32_t w = ring[(rd & (RING - 1)) * 64];
     ++rd;
@@ -246,21 +310,11 @@ struct RingSource {
   }
 };
 
-__device__ inline uint32_t get_bits4(uint64_t &x, RingSource &src) {
+__device__ __forceinline__ uint32_t get_bits4(uint64_t &x, RingSource &src) {
   const uint32_t val = (uint32_t)(x & 15u);
   x >>= 4;
   if (x < RANS_L) x = (x << 32) | src.next();
   return val;
-}
-
-// 16 B per lane, global -> LDS, no register round trip (LDS address = wave base + lane * 16); counted in vmcnt only.
-__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base) {
-  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(m0v)
-               : "memory");
 }
 
 template <int WAVES>
@@ -300,74 +354,134 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   // j - 1's stores.  `s_waitcnt vmcnt(SYM_BLK)` leaves exactly the youngest SYM_BLK operations - block j - 1's stores,
   // every block but the last stores all SYM_BLK - in flight and so guarantees granules j and j + 1 have landed, without
   // waiting for stores issued a moment ago.  (A ring refill drains everything; that only makes the counts smaller.)
+  // One symbol: bucket -> record (ONE 8-byte LDS read) -> three selects -> multiply-add -> renormalise, written on
+  // 32-bit halves in the order the dependence chain runs.  Everything a rare event needs (bounded search in the row,
+  // escape nibbles, ring refill) sits behind ONE wave-uniform branch.  `pack` / `offset`: the row's ImageMeta head.
+#ifdef LICOS_GC_STAMPS
+  long dbg_slow_n = 0, dbg_slow_cyc = 0, dbg_refill_cyc = 0, dbg_wait_cyc = 0;
+  const long dbg_t0 = clock64();
+#endif
+  auto step = [&](uint32_t row, uint32_t pack, int32_t offset) -> int32_t {
+    const uint32_t x_lo = (uint32_t)x, x_hi = (uint32_t)(x >> 32);
+    const uint32_t cf = x_lo & 0xFFFFu;
+    const uint2 r = *reinterpret_cast<const uint2 *>(s_img + (pack >> IMAGE_PACK_SHIFT) + ((cf >> (pack & 31u)) << 3));
+    // the next stream word is read before it is known to be needed: its LDS latency runs beside the lookup's
+    const uint32_t w_next = src.peek();
+    int s;
+    uint32_t off, freq;
+    bool miss;
+    image_pair(r, cf, s, off, freq, miss);
+    int32_t value;
+    // x = freq * (x >> 16) + (cf - start), then renormalise from the word read above
+    auto update = [&]() {
+      const uint32_t xs_lo = __builtin_amdgcn_alignbit(x_hi, x_lo, 16), xs_hi = x_hi >> 16;
+      uint64_t nx = (uint64_t)freq * xs_lo + off;
+      nx += (uint64_t)(freq * xs_hi) << 32;  // freq <= 2^16, xs_hi < 2^15
+      const bool need = nx < RANS_L;
+      x = need ? ((nx << 32) | w_next) : nx;
+      src.rd += need ? 1 : 0;
+    };
+    if (__builtin_expect(__any(miss), 0)) {  // uniform and rare: some stream's value lies outside its bucket's pair of symbols
+#ifdef LICOS_GC_STAMPS
+      const long st0 = clock64();
+      ++dbg_slow_n;
+#endif
+      bool escaped = false;
+      if (miss) {
+        const ImageMeta m = s_meta[row];
+        image_search(m, s_rec, s_cdf, r, cf, s, off, freq);
+        escaped = s == (int)(m.cdf_base_max >> 16);
+      }
+      update();
+      value = s;
+      if (escaped) {  // the row's escape symbol: the value follows as bypass nibbles
+        const int max_value = s;
+        uint32_t val = get_bits4(x, src);
+        int nbyp = (int)val;
+        while (val == 15u && nbyp < 64) { val = get_bits4(x, src); nbyp += (int)val; }
+        uint32_t raw = 0;
+        for (int t = 0; t < nbyp; ++t) {
+          const uint32_t nib = get_bits4(x, src);
+          if (t < 8) raw |= nib << (t * 4);
+        }
+        value = (int32_t)(raw >> 1);
+        value = (raw & 1u) ? -value - 1 : value + max_value;
+      }
+      src.refill_if_low();  // the escape path may have drained several words
+#ifdef LICOS_GC_STAMPS
+      dbg_slow_cyc += clock64() - st0;
+#endif
+    } else {
+      update();
+      value = s;
+    }
+    return value + offset;
+  };
+
+  const long nfull = n / SYM_BLK;  // whole blocks; a ragged tail is decoded symbol by symbol at the end
   dma16(ip, s_idx);
   if (nblk > 1) dma16(ip + (size_t)B, s_idx + 64);
-  for (long j = 0; j < nblk; ++j) {
+  for (long j = 0; j < nfull; ++j) {
+#ifdef LICOS_GC_STAMPS
+    const long sr0 = clock64();
+#endif
     src.refill_if_low();
+#ifdef LICOS_GC_STAMPS
+    const long sr1 = clock64();
+    dbg_refill_cyc += sr1 - sr0;
+#endif
     if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#ifdef LICOS_GC_STAMPS
+    dbg_wait_cyc += clock64() - sr1;
+#endif
     static_assert(SYM_BLK == 16, "the counted wait above is written for 16 stores per block");
-    const uint4 g = s_idx[(j & (IDEPTH - 1)) * 64 + lane];
+    const uint32_t *gp = reinterpret_cast<const uint32_t *>(s_idx + (j & (IDEPTH - 1)) * 64 + lane);
     if (j + 2 < nblk) dma16(ip + (size_t)(j + 2) * B, s_idx + ((j + 2) & (IDEPTH - 1)) * 64);
-    const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
-    int32_t outv[SYM_BLK];
-    const long i0 = j * SYM_BLK;
-    const int nb = (n - i0) < SYM_BLK ? (int)(n - i0) : SYM_BLK;
-    auto decode_block = [&](auto full_c) {
-      constexpr bool FULL = decltype(full_c)::value;
+    int32_t *op = sp + (size_t)(j * SYM_BLK) * ssi;
+    // four symbols per trip, NOT sixteen: unrolled further, the rare paths inlined behind every symbol push the loop
+    // past the 64 KB instruction cache and the hot path ends up waiting for its own code (measured: 245 -> ns/symbol)
+#pragma unroll 1
+    for (int q = 0; q < SYM_BLK / 4; ++q) {
+      const uint32_t gw = gp[q];
+      uint32_t pk[4];
+      int32_t of[4];
 #pragma unroll
-      for (int k = 0; k < SYM_BLK; ++k) {
-        outv[k] = 0;
-        if (!FULL && k >= nb) break;
-        const uint32_t c = (gw[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-        const ImageMeta m = s_meta[c];
-        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-        // the next stream word is read before it is known to be needed: its LDS latency runs beside the lookup's
-        const uint32_t w_next = src.peek();
-        int s;
-        uint32_t lo, him;
-        bool fb;
-        image_lookup(m, s_rec, s_cdf, cf, s, lo, him, fb);
-        x = (uint64_t)(him + 1u - lo) * (x >> 16) + cf - lo;
-        const bool need = x < RANS_L;
-        x = need ? ((x << 32) | w_next) : x;
-        src.advance(need);
-        const int max_value = (int)(m.cdf_base_max >> 16);
-        int32_t value = s;
-        if (__any(s == max_value)) {  // uniform and rare: some stream hit its row's escape symbol
-          if (s == max_value) {
-            uint32_t val = get_bits4(x, src);
-            int nbyp = (int)val;
-            while (val == 15u && nbyp < 64) { val = get_bits4(x, src); nbyp += (int)val; }
-            uint32_t raw = 0;
-            for (int t = 0; t < nbyp; ++t) {
-              const uint32_t nib = get_bits4(x, src);
-              if (t < 8) raw |= nib << (t * 4);
-            }
-            value = (int32_t)(raw >> 1);
-            value = (raw & 1u) ? -value - 1 : value + max_value;
-          }
-          src.refill_if_low();  // the escape path may have drained several words
-        }
-        outv[k] = value + (int32_t)m.offset;
+      for (int k = 0; k < 4; ++k) {  // the rows' metadata depends on the row bytes only: read off the state -> state chain
+        const uint2 mm = *reinterpret_cast<const uint2 *>(s_meta + ((gw >> (k * 8)) & 0xFFu));
+        pk[k] = mm.x;
+        of[k] = (int32_t)mm.y;
       }
-    };
-    if (nb == SYM_BLK) {
-      decode_block(std::true_type{});
+      int32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = step((gw >> (k * 8)) & 0xFFu, pk[k], of[k]);
       if (live) {
 #pragma unroll
-        for (int k = 0; k < SYM_BLK; ++k) {
-          int32_t *a = sp + (size_t)(i0 + k) * ssi;
-          asm volatile("global_store_dword %0, %1, off" ::"v"(a), "v"(outv[k]) : "memory");
+        for (int k = 0; k < 4; ++k) {
+          int32_t *a = op + (size_t)(q * 4 + k) * ssi;
+          asm volatile("global_store_dword %0, %1, off" ::"v"(a), "v"(v[k]) : "memory");
         }
       }
-    } else {  // the last, ragged block: nothing counts on its stores
-      decode_block(std::false_type{});
-      if (live)
-        for (int k = 0; k < nb; ++k) sp[(size_t)(i0 + k) * ssi] = outv[k];
     }
   }
-  if (live && src.over) atomicOr(status, 1);
+  if (nfull < nblk) {  // the last, ragged block: nothing counts on its stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    src.refill_if_low();
+    const uint8_t *gb = reinterpret_cast<const uint8_t *>(s_idx + (nfull & (IDEPTH - 1)) * 64 + lane);
+    for (long i = nfull * SYM_BLK; i < n; ++i) {
+      const uint32_t row = gb[i - nfull * SYM_BLK];
+      const uint2 mm = *reinterpret_cast<const uint2 *>(s_meta + row);
+      const int32_t v = step(row, mm.x, (int32_t)mm.y);
+      if (live) sp[(size_t)i * ssi] = v;
+    }
+  }
+#ifdef LICOS_GC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    long *d = reinterpret_cast<long *>(status + 2);
+    d[0] = clock64() - dbg_t0; d[1] = dbg_slow_n; d[2] = dbg_slow_cyc; d[3] = dbg_refill_cyc; d[4] = dbg_wait_cyc;
+  }
+#endif
+  if (live && (src.over || src.rd > src.nw)) atomicOr(status, 1);  // words past a stream's end read as zeros; flagged here
 }
 
 }  // namespace gc
@@ -380,10 +494,11 @@ using namespace licos::gc;
 namespace {
 
 // Mass of a row's 2^k buckets that the best adjacent-symbol pair per bucket does not cover (of 65536), and optionally
-// the records themselves.  c[0 .. len-1], c[len-1] == 65536, symbols 0 .. len-2.
+// the records themselves.  c[0 .. len-1], c[len-1] == 65536, symbols 0 .. len-2; the last symbol E (the escape) is
+// never part of a pair: its values always take the miss path.
 double row_records(const int32_t *c, int len, int k, uint2 *out) {
   const int shift = 16 - k, nb = 1 << k, width = 1 << shift;
-  const int last_sym = len - 2;
+  const int E = len - 2;
   long bad = 0;
   int f = 0;
   for (int j = 0; j < nb; ++j) {
@@ -392,18 +507,20 @@ double row_records(const int32_t *c, int len, int k, uint2 *out) {
     int l = f;
     while (c[l + 1] < key1) ++l;                        // l: symbol holding key1 - 1
     int best = f;
-    long best_cov = -1;
-    for (int s = f; s <= std::max(f, l - 1); ++s) {
-      const int hi = c[std::min(s + 2, len - 1)];
-      const long cov = (long)std::min(hi, key1) - std::max(c[s], key0);
-      if (cov > best_cov) { best_cov = cov; best = s; }
+    long best_cov = 0;
+    uint32_t f0 = 0, f1 = 0;
+    if (f < E) {
+      best_cov = -1;
+      for (int s = f; s <= std::min(std::max(f, l - 1), E - 1); ++s) {
+        const int hi = c[std::min(s + 2, E)];  // the pair ends where the escape symbol starts
+        const long cov = (long)std::min(hi, key1) - std::max(c[s], key0);
+        if (cov > best_cov) { best_cov = cov; best = s; }
+      }
+      f0 = (uint32_t)(c[best + 1] - c[best]);
+      f1 = best + 1 < E ? (uint32_t)(c[best + 2] - c[best + 1]) : 0u;
     }
     bad += width - best_cov;
-    if (out) {
-      const uint32_t c0 = (uint32_t)c[best], c1 = (uint32_t)c[std::min(best + 1, len - 1)], c2 = (uint32_t)c[std::min(best + 2, len - 1)];
-      out[j] = make_uint2((c0 & 0xFFFFu) | ((c1 - 1u) << 16), ((c2 - 1u) & 0xFFFFu) | ((uint32_t)best << 16));
-    }
-    (void)last_sym;
+    if (out) out[j] = make_uint2(((uint32_t)c[best] & 0xFFFFu) | (f0 << 16), (f1 & 0xFFFFu) | ((uint32_t)best << 16));
   }
   return (double)bad / 65536.0;
 }
@@ -473,7 +590,8 @@ int licos_rans_image_build(const int32_t *cdf, const int32_t *cdf_len, const int
   for (int r = 0; r < rows; ++r) {
     const int len = cdf_len[r];
     const int32_t *c = cdf + (size_t)r * stride;
-    meta[r] = ImageMeta{(uint32_t)rec_at, (uint32_t)(16 - k[r]), (uint32_t)cdf_at | ((uint32_t)(len - 2) << 16), (uint32_t)offset[r]};
+    meta[r] = ImageMeta{(uint32_t)((off_rec + rec_at * 8) << IMAGE_PACK_SHIFT) | (uint32_t)(16 - k[r]), offset[r],
+                        (uint32_t)cdf_at | ((uint32_t)(len - 2) << 16), (uint32_t)rec_at};
     row_records(c, len, k[r], rec + rec_at);
     for (int s = 0; s + 1 < len; ++s) c16[cdf_at + s] = (uint16_t)c[s];
     rec_at += 1L << k[r];
@@ -491,12 +609,12 @@ int licos_rans_image_lookup(const void *image, int row, int cf, int32_t *out3) {
   LICOS_REQUIRE(h.magic == IMAGE_MAGIC && row >= 0 && (uint32_t)row < h.rows && cf >= 0 && cf < 65536, "rans_image_lookup: bad image, row or value");
   const ImageMeta m = reinterpret_cast<const ImageMeta *>(blob + h.off_meta)[row];
   int s;
-  uint32_t lo, him;
+  uint32_t off, freq;
   bool fb;
-  image_lookup(m, reinterpret_cast<const uint2 *>(blob + h.off_rec), reinterpret_cast<const uint16_t *>(blob + h.off_cdf), (uint32_t)cf, s, lo, him, fb);
+  image_lookup(m, reinterpret_cast<const uint2 *>(blob + h.off_rec), reinterpret_cast<const uint16_t *>(blob + h.off_cdf), (uint32_t)cf, s, off, freq, fb);
   out3[0] = s;
-  out3[1] = (int32_t)lo;
-  out3[2] = (int32_t)(him + 1u);
+  out3[1] = (int32_t)((uint32_t)cf - off);
+  out3[2] = (int32_t)((uint32_t)cf - off + freq);
   return fb ? 1 : 0;
 }
 
@@ -516,12 +634,18 @@ int licos_gc_encode_prepare(const float *y, const float *scales, const float *sc
 int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint32_t *words, int cap_words, int32_t *nwords,
                               int32_t *status, int B, void *stream) {
   LICOS_REQUIRE(rec && aux && words && nwords && status && B > 0 && n > 0 && cap_words >= 2, "rans_encode_records: bad arguments");
-  // four waves per workgroup (one per SIMD, no table to share): 2048 streams occupy 8 CUs instead of 32
-  const int threads = B >= 256 ? 256 : 64 * cdiv(B, 64);
-  hipLaunchKernelGGL(rans_encode_records_kernel, dim3(cdiv(B, threads)), dim3(threads), 0, as_stream(stream),
-                     static_cast<const uint4 *>(rec), aux, n, words, cap_words, nwords, status, B);
-  LICOS_LAUNCH_CHECK();
-  return LICOS_OK;
+  LICOS_REQUIRE(((long)cap_words + 1) * B * 4 < (1L << 32), "rans_encode_records: scratch of %d x %d words exceeds 4 GB - code fewer streams per launch", cap_words + 1, B);
+  // two waves per workgroup: 2048 streams occupy 16 CUs (a CU that holds a coder wave cannot take a workgroup of the
+  // 8-wave transform kernels, and the coders run beside the neighbouring chunk's transforms)
+  auto launch = [&](auto kern, int waves) -> int {
+    const size_t lds = (size_t)waves * ENC_DEPTH * ENC_BATCH * 64 * sizeof(uint4);
+    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), lds, as_stream(stream), static_cast<const uint4 *>(rec), aux, n,
+                       words, cap_words, nwords, status, B);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  };
+  return B > 64 ? launch(rans_encode_records_kernel<2>, 2) : launch(rans_encode_records_kernel<1>, 1);
 }
 
 int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16, int B,

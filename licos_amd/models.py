@@ -140,12 +140,10 @@ class FactorizedPrior(CompressionModel):
         self._sync_precision()
         if x.shape[0] == 0:  # empty batch: nothing to launch
             return {"strings": [[]], "shape": torch.Size((x.shape[2] // 16, x.shape[3] // 16))}
-        if self.precision == "fp16":
-            from .codec import compress_fp16
-            return compress_fp16(self, x, chunk=self.chunk)
-        y = self.g_a(x)
-        y_strings = self.entropy_bottleneck.compress(y)
-        return {"strings": [y_strings], "shape": y.size()[-2:]}
+        # one pipeline for both precisions (licos_amd/codec.py): chunks of `self.chunk` tiles bound the activations - the
+        # fp32 parity path's first stage alone is 8.4 MB per 256 x 256 tile - and hide the serial coder under the transforms
+        from .codec import compress_chunked
+        return compress_chunked(self, x, chunk=self.chunk if self.precision == "fp16" else min(self.chunk, 1024))
 
     def decompress(self, strings, shape):
         assert isinstance(strings, list) and len(strings) == 1
@@ -154,12 +152,8 @@ class FactorizedPrior(CompressionModel):
             dev = self.entropy_bottleneck.quantiles.device
             cout = self.g_s[len(self.g_s) - 1].out_channels
             return {"x_hat": torch.zeros((0, cout, int(shape[0]) * 16, int(shape[1]) * 16), device=dev)}
-        if self.precision == "fp16":
-            from .codec import decompress_fp16
-            return decompress_fp16(self, strings, shape, chunk=self.chunk)
-        y_hat = self.entropy_bottleneck.decompress(strings[0], shape)
-        x_hat = self.g_s(y_hat).clamp_(0, 1)
-        return {"x_hat": x_hat}
+        from .codec import decompress_chunked
+        return decompress_chunked(self, strings, shape, chunk=self.chunk if self.precision == "fp16" else min(self.chunk, 1024))
 
     @classmethod
     def from_state_dict(cls, state_dict):

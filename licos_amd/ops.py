@@ -581,12 +581,12 @@ def rans_encode_records(rec, aux, cap_words):
     """The serial encoder over prepared records: (words [cap_words][B], nwords [B], status [1])."""
     _dev(rec, aux)
     n, b = aux.shape
-    words = torch.empty((cap_words, b), device=aux.device, dtype=torch.int32)
+    words = torch.empty((cap_words + 1, b), device=aux.device, dtype=torch.int32)  # row 0: the kernel's dump row
     nwords = torch.empty(b, device=aux.device, dtype=torch.int32)
     status = torch.zeros(1, device=aux.device, dtype=torch.int32)
     rc = _lib.load().licos_rans_encode_records(_p(rec), _p(aux), n, _p(words), cap_words, _p(nwords), _p(status), b, _stream())
     _lib.check(rc, "rans_encode_records")
-    return words, nwords, status
+    return words[1:], nwords, status
 
 
 def gc_decode_prepare(scales, scale_table, scale_bound):

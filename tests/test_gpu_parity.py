@@ -294,6 +294,52 @@ def test_full_size_tiles_fp32_vs_oracle(cin, kind):
                    - om.compute_psnr(ref["x_hat"].clamp(0, 1), x)) < 1e-3
 
 
+@pytest.mark.parametrize("cin,kind", [(3, "aid"), (13, "s2-merged"), (1, "s2")])
+def test_fp32_chunk_pipeline_seams_match_oracle(cin, kind, monkeypatch):
+    """The strict-parity (fp32) path through the chunk pipeline (licos_amd/codec.py; what eval_utils.py:199-201's
+    compress call runs for a large batch): 5 tiles in chunks of 2 - tiles on both sides of two seams and a ragged last
+    chunk.  A tile's bytes must not depend on the chunking, must equal the oracle's wherever no latent sits on a
+    rounding tie, and the oracle's decoder must read every stream back to the GPU's own symbols."""
+    monkeypatch.setattr(ops, "HOST_CODER", "0")  # the pipeline is the device-coder path
+    sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=13)
+    net = _load(cin, sd)
+    eb = net.entropy_bottleneck
+    om.eb_update(sd)
+    x = om.synthetic_tiles(5, cin, 64, seed=21, kind=kind)
+    ref = om.forward(x, sd)
+    ref_c = om.compress(x, sd)
+    med = sd["entropy_bottleneck.quantiles"][:, 0, 1]
+    with torch.no_grad():
+        net.chunk = 2
+        comp = net.compress(x.to(DEV))
+        dec = net.decompress(comp["strings"], comp["shape"])
+        dec_plain = net.decompress([[bytes(s) for s in comp["strings"][0]]], comp["shape"])  # re-chunked from plain bytes
+        net.chunk = 8
+        comp_whole = net.compress(x.to(DEV))
+        dec_whole = net.decompress(comp_whole["strings"], comp_whole["shape"])
+        y = net.g_a(x.to(DEV))
+        out = net(x.to(DEV))
+    assert list(comp["strings"][0]) == list(comp_whole["strings"][0])
+    assert torch.equal(dec["x_hat"], dec_whole["x_hat"]) and torch.equal(dec["x_hat"], dec_plain["x_hat"])
+    assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
+    b, c, h, w = y.shape
+    sym = eb._symbols_interleaved(y).cpu().T.reshape(b, c, h, w)
+    cdf, cdf_len, offset = (sd["entropy_bottleneck." + k].numpy() for k in ("_quantized_cdf", "_cdf_length", "_offset"))
+    idx = np.repeat(np.arange(c, dtype=np.int32), h * w)
+    exact = 0
+    for i in range(b):
+        tie = tie_mismatches(sym[i:i + 1], ref["y"][i:i + 1], med, tol=2e-5 * float(ref["y"].abs().max()))
+        if tie == 0:
+            assert comp["strings"][0][i] == ref_c["strings"][0][i], f"tile {i}"
+            exact += 1
+        assert comp["strings"][0][i] == rans.encode_with_indexes(sym[i].reshape(-1).numpy(), idx, cdf, cdf_len, offset)
+        assert np.array_equal(rans.decode_with_indexes(comp["strings"][0][i], idx, cdf, cdf_len, offset), sym[i].reshape(-1).numpy())
+    assert exact >= 3  # ties are rare: most tiles, on both sides of a seam, match the oracle byte for byte
+    ref_d = om.decompress(ref_c["strings"], ref_c["shape"], sd)
+    if exact == b:
+        assert rel_err(dec["x_hat"], ref_d["x_hat"]) < 1e-5
+
+
 def test_ragged_and_empty_inputs():
     sd = om.perturb_state(om.make_factorized_state(3, 1), seed=2)
     net = _load(3, sd)

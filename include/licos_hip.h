@@ -97,7 +97,8 @@ int licos_conv2d_wgrad_f32(const float *inp /*[B][Ci][H][W]*/, const float *g /*
                            int Ci, int H, int W, int Co, int K, int stride, int pad, int square_input, void *stream);
 /* The GDN gamma gradient (the 1x1, square_input case above) for 128 channels on the matrix cores:
  * dgamma_eff[i][j] = sum_{b,p} t[b][i][p] * x[b][j][p]^2, fp32-grade through the three-pass fp16 split, partial matrices per
- * workgroup added in a fixed order (bit-reproducible).  scratch: licos_gdn_gamma_grad_parts(B, HW) * 128 * 128 floats. */
+ * workgroup added in a fixed order (bit-reproducible); t is staged as t * 2^k, k from a max|t| pre-pass, so gradients far
+ * below fp16's range (1e-6 .. 1e-12) keep their bits.  scratch: licos_gdn_gamma_grad_parts(B, HW) * 128 * 128 + 4 floats. */
 int licos_gdn_gamma_grad_parts(int B, long HW);
 int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream);
 int licos_bias_grad_f32(const float *dy /*[B][C][HW]*/, float *db /*[C]*/, int B, int C, long HW, void *stream);
@@ -388,6 +389,11 @@ int licos_comm_unique_id(void *out128);
 int licos_comm_init(void **comm, int nranks, int rank, const void *id128);
 int licos_comm_destroy(void *comm);
 int licos_allreduce_weighted(float *bucket, long n, float coef, void *comm, void *stream);
+/* The same blend on the direct schedule (xGMI is a point-to-point mesh): grouped ncclSend / ncclRecv of
+ * per-rank chunks, a fixed-order local reduction, grouped exchange of the reduced chunks - two steps instead of a ring's
+ * 2 (N - 1).  n_alloc >= nranks * ceil(n / nranks) elements addressable behind `bucket`; scratch: that many floats. */
+int licos_allreduce_weighted_direct(float *bucket, long n, long n_alloc, float coef, void *comm, int nranks, int rank,
+                                    float *scratch, void *stream);
 
 #define LICOS_EPI_NONE 0
 #define LICOS_EPI_GDN 1

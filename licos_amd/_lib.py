@@ -66,6 +66,7 @@ SIGNATURES = {
     "licos_comm_init": (_i, [_vp, _i, _i, _vp]),
     "licos_comm_destroy": (_i, [_vp]),
     "licos_allreduce_weighted": (_i, [_vp, _l, _f, _vp, _vp]),
+    "licos_allreduce_weighted_direct": (_i, [_vp, _l, _l, _f, _vp, _i, _i, _vp, _vp]),
     "licos_scale_f32": (_i, [_vp, _l, _f, _vp, _vp]),
     "licos_packed_conv_w_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_conv_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -6,13 +6,15 @@ Checkpoints: the dict LICOS writes - {"batch_idx", "state_dict", "loss", "local_
 are CompressAI's, so files move between the two implementations.
 
 Bit streams, two containers:
-* ``write_image`` / ``read_image``: ONE image per record in the byte layout of CompressAI's ``examples/codec.py``
-  (``_encode_image`` / ``_decode_image``: two header bytes - model id, (metric << 4) | (quality - 1) -, the original
-  size as two big-endian uint32, then ``write_body``: latent shape (2 x uint32), the number of string lists (uint32) and
-  per list the length (uint32) and bytes of its string).  Such a file is what ``python -m compressai.utils... codec
-  decode`` style tools read for the same model and weights.  The model-id table is CompressAI's zoo order, which differs
-  between releases (``bmshj2018-factorized-relu`` was inserted at index 1); both tables are provided.  CompressAI is
-  absent from this image, so the layout is restated from its published source, not verified against the tool.
+* ``write_image`` / ``read_image``: ONE image per record, **codec.py-style**: the byte layout of the EARLY releases of
+  CompressAI's ``examples/codec.py`` (``_encode_image`` / ``_decode_image``: two header bytes - model id, (metric << 4) |
+  (quality - 1) -, the original size as two big-endian uint32, then ``write_body``: latent shape (2 x uint32), the
+  number of string lists (uint32) and per list the length (uint32) and bytes of its string).  NOT claimed interchangeable
+  with the tool: CompressAI is absent from this image, the layout is restated from its published source and has never
+  met a file the tool wrote; later releases of codec.py (the ones whose zoo carries ``bmshj2018-factorized-relu``, i.e.
+  the ``ids="current"`` table below) are believed to add a codec-type byte to the header and a bit-depth byte after the
+  size, which this container does not write.  The two model-id tables exist because the zoo order - hence the id of
+  every model after index 0 - differs between those releases; pick ``ids="legacy"`` for the layout written here.
 * ``write_strings`` / ``read_strings``: a whole ``compress()`` result (a batch of tiles) in one stream: the same body
   fields with a leading magic and batch count - a licos_amd format, because codec.py has no notion of a batch."""
 import os

@@ -311,11 +311,7 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
   hipLaunchKernelGGL(transpose_sq_f32_kernel, dim3(cdiv((long)C * C, 256)), dim3(256), 0, as_stream(stream), gamma_eff,
                      gamma_t_scratch, C);
   LICOS_LAUNCH_CHECK();
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gdn_bwd_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(gdn_bwd_f32_kernel, 160 * 1024);
   hipLaunchKernelGGL(gdn_bwd_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, dy, gamma_eff,
                      gamma_t_scratch, beta_eff, dx, t_out, C, HW, inverse, keep_n);
   LICOS_LAUNCH_CHECK();

@@ -22,6 +22,10 @@ struct Rccl {
   int (*CommInitRank)(ncclComm_t *, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
@@ -46,7 +50,12 @@ Rccl &rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString && r.Send && r.Recv &&
+           r.GroupStart && r.GroupEnd;
   });
   return r;
 }
@@ -60,6 +69,17 @@ __global__ void scale_and_tag_kernel(float *__restrict__ x, long n, float coef) 
 __global__ void normalise_kernel(float *__restrict__ x, long n) {
   const float inv = 1.0f / x[n - 1];
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n - 1; e += (long)gridDim.x * blockDim.x) x[e] *= inv;
+}
+
+// own[i] += sum over the peers p != rank, in ascending p, of scratch[p * chunk + i]  (fixed order: every rank computes
+// ITS chunk once and ships the result, so all ranks end with identical bits)
+__global__ void reduce_peers_kernel(float *__restrict__ own, const float *__restrict__ scratch, long chunk, int nranks, int rank) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < chunk; e += (long)gridDim.x * blockDim.x) {
+    float acc = own[e];
+    for (int p = 0; p < nranks; ++p)
+      if (p != rank) acc += scratch[(size_t)p * chunk + e];
+    own[e] = acc;
+  }
 }
 
 }  // namespace
@@ -108,6 +128,48 @@ int licos_allreduce_weighted(float *bucket, long n, float coef, void *comm, void
   hipLaunchKernelGGL(scale_and_tag_kernel, dim3(blocks), dim3(256), 0, s, bucket, n, coef);
   LICOS_LAUNCH_CHECK();
   LICOS_NCCL_CHECK(rccl().AllReduce(bucket, bucket, (size_t)n, kNcclFloat32, kNcclSum, static_cast<ncclComm_t>(comm), s), "allreduce_weighted");
+  hipLaunchKernelGGL(normalise_kernel, dim3(blocks), dim3(256), 0, s, bucket, n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+// The same blend on the DIRECT schedule: xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per
+// GPU), so a 12 MB bucket does not need a ring's 2 (N - 1) dependent steps.  Two steps, every link busy in both:
+//   1. rank r sends chunk p of its (scaled) bucket to rank p, for every peer, and receives the peers' chunk r  (grouped
+//      ncclSend / ncclRecv); it adds them to its own chunk r in a fixed order
+//   2. rank r sends the reduced chunk r to every peer and receives theirs in place
+// `n_alloc` >= nranks * ceil(n / nranks) elements must be addressable behind `bucket` (the tail past n is padding the
+// caller owns); `scratch`: nranks * ceil(n / nranks) floats.
+int licos_allreduce_weighted_direct(float *bucket, long n, long n_alloc, float coef, void *comm, int nranks, int rank,
+                                    float *scratch, void *stream) {
+  LICOS_REQUIRE(bucket && scratch && n >= 2 && comm && nranks >= 1 && rank >= 0 && rank < nranks, "allreduce_weighted_direct: bad arguments");
+  LICOS_REQUIRE(rccl().ok, "allreduce_weighted_direct: librccl.so could not be loaded");
+  const long chunk = (n + nranks - 1) / nranks;
+  LICOS_REQUIRE(n_alloc >= chunk * nranks, "allreduce_weighted_direct: the bucket must be padded to %ld elements (%d ranks)", chunk * nranks, nranks);
+  hipStream_t s = as_stream(stream);
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_and_tag_kernel, dim3(blocks), dim3(256), 0, s, bucket, n, coef);
+  LICOS_LAUNCH_CHECK();
+  if (nranks > 1) {
+    LICOS_NCCL_CHECK(rccl().GroupStart(), "allreduce_weighted_direct");
+    for (int p = 0; p < nranks; ++p) {
+      if (p == rank) continue;
+      LICOS_NCCL_CHECK(rccl().Send(bucket + (size_t)p * chunk, (size_t)chunk, kNcclFloat32, p, c, s), "allreduce_weighted_direct");
+      LICOS_NCCL_CHECK(rccl().Recv(scratch + (size_t)p * chunk, (size_t)chunk, kNcclFloat32, p, c, s), "allreduce_weighted_direct");
+    }
+    LICOS_NCCL_CHECK(rccl().GroupEnd(), "allreduce_weighted_direct");
+    const int rb = (int)((chunk + 255) / 256 < 2048 ? (chunk + 255) / 256 : 2048);
+    hipLaunchKernelGGL(reduce_peers_kernel, dim3(rb), dim3(256), 0, s, bucket + (size_t)rank * chunk, scratch, chunk, nranks, rank);
+    LICOS_LAUNCH_CHECK();
+    LICOS_NCCL_CHECK(rccl().GroupStart(), "allreduce_weighted_direct");
+    for (int p = 0; p < nranks; ++p) {
+      if (p == rank) continue;
+      LICOS_NCCL_CHECK(rccl().Send(bucket + (size_t)rank * chunk, (size_t)chunk, kNcclFloat32, p, c, s), "allreduce_weighted_direct");
+      LICOS_NCCL_CHECK(rccl().Recv(bucket + (size_t)p * chunk, (size_t)chunk, kNcclFloat32, p, c, s), "allreduce_weighted_direct");
+    }
+    LICOS_NCCL_CHECK(rccl().GroupEnd(), "allreduce_weighted_direct");
+  }
   hipLaunchKernelGGL(normalise_kernel, dim3(blocks), dim3(256), 0, s, bucket, n);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

@@ -35,4 +35,14 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 constexpr int WAVE = 64;
 
+// Raises a kernel's dynamic-LDS limit to `bytes` on the CURRENT device, once per (device, kernel): the library is
+// re-entrant per (device, stream) - a process-wide "already set" flag would skip the other devices of a
+// multi-device process and race between threads.  host.cpp; returns a LICOS_* code.
+int ensure_dynamic_lds(const void *kernel, int bytes);
+#define LICOS_ENSURE_LDS(kernel, bytes)                                                  \
+  do {                                                                                   \
+    const int rc_ = ::licos::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), (int)(bytes)); \
+    if (rc_ != LICOS_OK) return rc_;                                                     \
+  } while (0)
+
 }  // namespace licos

@@ -65,6 +65,12 @@ __global__ void eb_pack_kernel(EbPackArgs a, EbShape s, int C, float *__restrict
   }
 }
 
+// A workgroup's partial sum of log2-likelihoods, snapped to a multiple of 2^-20 before it is added to the per-image total
+// with a double atomicAdd: sums of such multiples below 2^32 are exact in a double, hence independent of the order the
+// workgroups arrive in - the total is bit-reproducible from run to run, like every other reduction of the training path
+// (each partial itself is summed in a fixed order).  Costs < 5e-7 bit per workgroup.
+__device__ inline double fixed_point_partial(double t) { return rint(t * 1048576.0) * (1.0 / 1048576.0); }
+
 // ---- quantise ---------------------------------------------------------------------------------
 __global__ void eb_quantize_kernel(const float *__restrict__ y, const float *__restrict__ medians,
                                    const float *__restrict__ noise, float *__restrict__ y_hat,
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void eb_likelihood_kernel(const float *__restr
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
-      atomicAdd(&sum_log2[b], t);
+      atomicAdd(&sum_log2[b], fixed_point_partial(t));
     }
   }
 }
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256) void gc_likelihood_kernel(const float *__restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_red[wave] = local;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sum_log2[b], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) atomicAdd(&sum_log2[b], fixed_point_partial(s_red[0] + s_red[1] + s_red[2] + s_red[3]));
   }
 }
 

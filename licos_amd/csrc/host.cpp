@@ -4,6 +4,9 @@
 
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -21,6 +24,18 @@ int fail(int code, const char *fmt, ...) {
   va_end(ap);
   last_error_ref() = buf;
   return code;
+}
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> done;  // (device, kernel) -> limit already granted
+  int dev = 0;
+  LICOS_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int &have = done[std::make_pair(dev, kernel)];
+  if (have >= bytes) return LICOS_OK;
+  LICOS_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+  return LICOS_OK;
 }
 }  // namespace licos
 

@@ -281,6 +281,9 @@ int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStrea
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_deconv8.hip; 1 = not applicable
 int mfma_try_conv3x3_tiles(const MfmaArgs &a, int MT, int epi, hipStream_t s);  // mfma_conv3x3t.hip; 1 = not applicable
 bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv);
+// 9 .. 16 output channels over a whole number of channel PAIRS of chunks: the 16 x 16 x 32 kernel and its weight layout
+// ([pair][tap][lane][8]); everything else: the 32-row kernel and its compact layout.  One rule for packer and launcher.
+inline bool fewch_uses_16x16x32(int Cin, int Cout) { return Cout > 8 && Cout <= 16 && Cin % 32 == 0; }
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 
 }  // namespace licos

@@ -128,11 +128,7 @@ static int launch_conv(const MfmaArgs &a0, hipStream_t s) {
   // gamma fragments share the K-loop buffers' space; only (I)GDN epilogues need room for them
   const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)2 * G::BUF_GRAN * 16;
   auto kern = conv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();

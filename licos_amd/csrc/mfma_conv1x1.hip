@@ -70,11 +70,7 @@ static int launch_conv1x1(const MfmaArgs &a, int HW, hipStream_t s) {
   constexpr int NT = (MT <= 4) ? 2 : 1;
   const size_t lds = (size_t)MT * CC * 64 * 16;
   auto kern = conv1x1_mfma_kernel<MT, CC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(cdiv(HW, 4 * 32 * NT), a.B), dim3(256), lds, s, a, HW);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

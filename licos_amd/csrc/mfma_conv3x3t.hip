@@ -131,11 +131,7 @@ static int launch_conv3x3t(const MfmaArgs &a0, hipStream_t s) {
   const int run = tiles >= 8 ? 8 : tiles;  // tiles per workgroup
   const size_t lds = (size_t)16 * (2 * G::PATCH_PAD + G::W_GRAN_MAX + 16 * MT + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
   auto kern = conv3x3s1_tiles_kernel<MT, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)cdiv(tiles, run) * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "conv3x3s1_f16: grid too large");
   LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 < (1L << 32), "conv3x3s1_f16: an image's output must stay below 4 GB (32-bit store offsets)");

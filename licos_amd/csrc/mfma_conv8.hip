@@ -247,11 +247,7 @@ static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
   const size_t lds = TILE_EPI ? (size_t)(G::TOTAL_GRAN + G::GAMMA_GRAN) * 16 + 2 * 32 * MT * sizeof(float)
                               : (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::TOTAL_GRAN * 16;
   auto kern = conv5x5s2_mfma8_kernel<MT, EPI, false, TILE_EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
   LICOS_REQUIRE(!TILE_EPI || (long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 < (1L << 32), "conv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(512), lds, s, a);
@@ -269,11 +265,7 @@ static int launch_conv8_pair(const MfmaArgs &a0, int mt_total, hipStream_t s) {
   a.halves = mt_total / MT;
   auto kern = conv5x5s2_mfma8_kernel<MT, EPI, true>;
   const size_t lds = (size_t)G::TOTAL_GRAN * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)((a.B + 1) / 2) * a.tiles_y * a.halves;
   LICOS_REQUIRE(blocks < (1L << 31), "conv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);

@@ -155,11 +155,7 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
   // gamma fragments share the K-loop buffers' space; only (I)GDN epilogues need room for them
   const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::KLOOP_GRAN * 16;
   auto kern = deconv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4) * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, a);
@@ -334,6 +330,156 @@ __global__ __launch_bounds__(256, 2) void deconv5x5s2_fewch_kernel(MfmaArgs a) {
   }
 }
 
+// ---- the same stage for 5 .. 16 output channels (the 13-band Sentinel-2 models) on v_mfma_f32_16x16x32_f16 -----------
+// With 13 output channels a 32-row MFMA tile is 60 % zeros and the kernel above is MFMA-bound on padding (1.0 PFLOP/s
+// of issued work, 0.4 useful).  The 16 x 16 x 32 shape has 16 rows: K = 32 = TWO cin chunks of 16 channels per step
+// (lane k-group g = lane / 16: chunk g / 2 of the pair, half g % 2), so the nine shifted patch views of a pixel tile are
+// still loaded once per step and shared by all 25 taps, and the matrix pipes do a quarter of the cycles per useful MAC.
+// 8 waves own a 16 x 32 input tile (wave w: rows 2w, 2w + 1 as four 16-pixel tiles), all four output phases in registers
+// (4 x 4 x 4 accumulators), patch and weights of a chunk PAIR staged by LDS-DMA; two workgroups per CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Few16Geom {
+  static constexpr int TH = 16, TW = 32;
+  using G = DeconvGeom<TH, TW>;
+  static constexpr int HALF = round_up(G::PH * G::RS, 32);  // granules of one 8-channel half of one chunk's patch
+  static constexpr int CHUNK_GRAN = 2 * HALF;
+  static constexpr int PATCH_GRAN = 2 * CHUNK_GRAN;         // two chunks per K step
+  static constexpr int W_GRAN = 25 * 64;                    // one A fragment (64 lanes x 16 B) per tap
+  static constexpr int BUF_GRAN = PATCH_GRAN + W_GRAN;
+  static_assert(PATCH_GRAN % 64 == 0, "patch must be whole LDS-DMA pieces");
+};
+
+__global__ __launch_bounds__(512, 4) void deconv5x5s2_few16_kernel(MfmaArgs a) {
+  using F = Few16Geom;
+  using G = F::G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_buf = reinterpret_cast<half8 *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px_l = lane & 15, g = lane >> 4;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int ty0 = (tile / a.tiles_x) * F::TH, tx0 = (tile % a.tiles_x) * F::TW;
+
+  // pixel tile t of this wave: row 2 wave + t / 2, columns 16 (t % 2) .. + 15; this lane's granule at tap offset (0, 0)
+  int base[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    base[t] = (g >> 1) * F::CHUNK_GRAN + (g & 1) * F::HALF + (2 * wave + (t >> 1) + 1) * G::RS + (16 * (t & 1) + px_l + 1);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const size_t plane = (size_t)a.H * a.W;
+  const half8 *xb = reinterpret_cast<const half8 *>(a.x) + (size_t)b * a.Cin16 * plane * 2;
+  const half8 *zero = reinterpret_cast<const half8 *>(a.zero16);
+  const int npairs = a.Cin16 / 2;
+
+  constexpr int PQ = F::PATCH_GRAN / 64, NPP = (PQ + 7) / 8, NWP = (25 + 7) / 8;
+  const half8 *p_src[NPP];
+  bool p_ok[NPP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int d = (wave + 8 * i) * 64 + lane;
+    const int cc = d / F::CHUNK_GRAN, r1 = d - cc * F::CHUNK_GRAN;
+    const int hh = r1 / F::HALF, rem = r1 - hh * F::HALF;
+    const int j = rem / G::RS, q = rem - j * G::RS;
+    const int yy = ty0 - 1 + j, xx = tx0 - 1 + q;
+    p_ok[i] = d < F::PATCH_GRAN && j < G::PH && q < G::PW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    p_src[i] = xb + ((size_t)cc * plane + (ptrdiff_t)yy * a.W + xx) * 2 + hh;
+  }
+  auto stage = [&](int pair, int buf) {
+    half8 *dst = s_buf + buf * F::BUF_GRAN;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int q = wave + 8 * i;
+      if (q < PQ) glds16(p_ok[i] ? p_src[i] + (size_t)pair * 2 * plane * 2 : zero, dst + q * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int q = wave + 8 * i;
+      if (q < 25) glds16(a.wp + ((size_t)pair * 25 + q) * 64 + lane, dst + F::PATCH_GRAN + q * 64);
+    }
+  };
+
+  // ONE buffer per workgroup (69 KB): two workgroups share a CU and fill each other's gaps - one stages or stores while the
+  // other multiplies - which a double buffer inside a single resident workgroup (137 KB, nothing beside it) did not do:
+  // its output stores (106 KB of fp32 per tile) and its first stage overlapped with nothing (5.6 ms per 512 tiles; this form
+  // is measured in DESIGN.md section 5).
+  for (int pair = 0; pair < npairs; ++pair) {
+    if (pair) __builtin_amdgcn_s_barrier();  // every wave has read the previous pair's fragments
+    stage(pair, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const half8 *s_patch = s_buf;
+    const half8 *s_w = s_patch + F::PATCH_GRAN + lane;
+    // kernel row iky reads the patch at dy = 1 - iky, kernel column ikx at dx = 1 - ikx, whatever the phase: a shifted
+    // view of the four pixel tiles is loaded once and serves every phase's tap at that (iky, ikx)
+#pragma unroll
+    for (int iky = 0; iky < 3; ++iky) {
+#pragma unroll
+      for (int ikx = 0; ikx < 3; ++ikx) {
+        half8 bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = s_patch[base[t] + (1 - iky) * G::RS + (1 - ikx)];
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          if (iky >= (py ? 2 : 3)) continue;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int ph = 2 * py + px, nkx = px ? 2 : 3;
+            if (ikx >= nkx) continue;
+            const int tap0 = ph == 0 ? 0 : ph == 1 ? 9 : ph == 2 ? 15 : 21;  // phase-major tap order of the packed weights
+            const half8 af = s_w[(tap0 + iky * nkx + ikx) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[ph][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[t], acc[ph][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // store: register i of a lane is channel 4 g + i of pixel px_l; the two column phases of one output row go out as a pair
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int iy = ty0 + 2 * wave + (t >> 1), ix = tx0 + 16 * (t & 1) + px_l;
+    if (iy >= a.H || ix >= a.W) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * g + i;
+      if (c >= a.Cout) continue;
+      const float bias = a.bias[c];
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float2 v;
+        v.x = acc[2 * py][t][i] + bias;
+        v.y = acc[2 * py + 1][t][i] + bias;
+        if (a.clamp01) {
+          v.x = fminf(fmaxf(v.x, 0.f), 1.f);
+          v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+        }
+        float *dst = a.y_nchw + (((size_t)b * a.Cout + c) * a.Ho + 2 * iy + py) * a.Wo + 2 * ix;
+        *reinterpret_cast<float2 *>(dst) = v;
+      }
+    }
+  }
+}
+
+static int launch_few16(const MfmaArgs &a0, hipStream_t s) {
+  using F = Few16Geom;
+  MfmaArgs a = a0;
+  a.tiles_x = cdiv(a.W, F::TW);
+  a.tiles_y = cdiv(a.H, F::TH);
+  const size_t lds = (size_t)F::BUF_GRAN * 16;
+  LICOS_ENSURE_LDS(deconv5x5s2_few16_kernel, lds);
+  LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "deconv5x5s2_f16: grid too large");
+  hipLaunchKernelGGL(deconv5x5s2_few16_kernel, dim3(a.tiles_x * a.tiles_y * a.B), dim3(512), lds, s, a);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 template <int RP>
 static int launch_fewch(const MfmaArgs &a0, hipStream_t s) {
   using G = DeconvGeom<8, 32>;
@@ -344,11 +490,7 @@ static int launch_fewch(const MfmaArgs &a0, hipStream_t s) {
   a.tiles_y = cdiv(a.H, 8);
   const size_t lds = (size_t)2 * BUF_GRAN * 16;
   auto kern = deconv5x5s2_fewch_kernel<2, 8, 32, RP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "deconv5x5s2_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3(a.tiles_x * a.tiles_y * a.B), dim3(256), lds, s, a);
   LICOS_LAUNCH_CHECK();
@@ -359,6 +501,7 @@ static int launch_fewch(const MfmaArgs &a0, hipStream_t s) {
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s) {
   if (a.Cout <= 4) return launch_fewch<4>(a, s);
   if (a.Cout <= 8) return launch_fewch<8>(a, s);
+  if (fewch_uses_16x16x32(a.Cin16 * 16, a.Cout)) return launch_few16(a, s);  // (same rule as the weight packer)
   if (a.Cout <= 16) return launch_fewch<16>(a, s);
   return launch_fewch<32>(a, s);
 }

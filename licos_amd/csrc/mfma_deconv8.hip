@@ -213,11 +213,7 @@ static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
   a.tiles_y = cdiv(a.H, G::TH);
   const size_t lds = (size_t)16 * (G::KLOOP_GRAN + 16 * MT + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
   auto kern = deconv5x5s2_mfma8_kernel<MT, EPI, PAIR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)a.tiles_x * a.tiles_y * (PAIR ? (a.B + 1) / 2 : a.B);  // a workgroup walks all four phases of its tile
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
   LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 * (PAIR ? 2 : 1) < (1L << 32), "deconv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");

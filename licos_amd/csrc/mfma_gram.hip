@@ -6,7 +6,10 @@
 //
 // fp32 accuracy through the three-pass split: every value v is staged in LDS as hi = fp16(v) and
 // lo = fp16((v - hi) * 2^11); D = hi.hi + 2^-11 (hi.lo + lo.hi), the two parts in separate accumulators.  x^2 is staged as
-// (x / 16)^2 (and the result multiplied by 256) so that activations in the hundreds stay inside fp16, as in the forward norm.
+// (x / 16)^2 (and the result multiplied by 256) so that activations in the hundreds stay inside fp16, as in the forward norm;
+// t - a loss gradient, 1e-6 .. 1e-9 per element for a mean-reduced rate-distortion loss, i.e. BELOW fp16's normal range -
+// is staged as t * 2^k with k chosen by a pre-pass from max|t| so that the largest magnitude lands near 2^14: values down
+// to 2^-28 of the maximum keep a normal high part (exact: a power of two), the result is multiplied by 2^-k.
 // A workgroup (4 waves; wave w owns output rows 32w .. 32w+31, all 128 columns) walks a contiguous range of 32-pixel
 // slabs and writes ONE partial matrix; a second kernel adds the partials in workgroup order (no atomics: the gradient is
 // bit-reproducible).
@@ -18,7 +21,7 @@ constexpr int GR_C = 128, GR_PT = 32, GR_ROW = GR_PT / 8 + 1;  // 5 granules per
 
 // stage one slab: [2 tensors][hi, lo][128 channels][GR_ROW granules of 8 pixels]
 __device__ inline void gram_stage(const float *__restrict__ t, const float *__restrict__ x, size_t img_off, long HW, long p0,
-                                  half8 *s, int tid) {
+                                  half8 *s, int tid, float t_scale) {
   // 2 tensors x 128 channels x 4 granules = 1024 granule jobs over 256 threads; a job = 8 consecutive pixels (two float4)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -37,7 +40,7 @@ __device__ inline void gram_stage(const float *__restrict__ t, const float *__re
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float val = which ? (v[e] * 0.0625f) * (v[e] * 0.0625f) : v[e];
+      const float val = which ? (v[e] * 0.0625f) * (v[e] * 0.0625f) : v[e] * t_scale;
       hi[e] = (_Float16)val;
       lo[e] = (_Float16)((val - (float)hi[e]) * 2048.f);
     }
@@ -46,8 +49,32 @@ __device__ inline void gram_stage(const float *__restrict__ t, const float *__re
   }
 }
 
+// max |t| as the bit pattern of a non-negative float (ordered like an unsigned integer)
+__global__ void gram_absmax_kernel(const float *__restrict__ t, long n, unsigned int *__restrict__ out) {
+  unsigned int m = 0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const unsigned int b = __float_as_uint(t[e]) & 0x7FFFFFFFu;
+    m = b > m && b < 0x7F800000u ? b : m;  // (infinities / NaNs do not choose the scale)
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned int o = __shfl_xor(m, off);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// 2^k with max|t| * 2^k in [2^13, 2^14)  (1 when t is all zero)
+__device__ inline float gram_t_scale(unsigned int absmax_bits) {
+  if (absmax_bits == 0) return 1.f;
+  const int e = (int)(absmax_bits >> 23) - 127;  // floor(log2(max)) (denormal maxima: e = -127, clamped below)
+  int k = 13 - e;
+  k = k > 120 ? 120 : (k < -120 ? -120 : k);
+  return __uint_as_float((unsigned int)(127 + k) << 23);
+}
+
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restrict__ t, const float *__restrict__ x, float *__restrict__ part,
-                                                          int B, long HW, int slabs_per_image, int slabs_per_wg) {
+                                                          const unsigned int *__restrict__ absmax, int B, long HW, int slabs_per_image,
+                                                          int slabs_per_wg) {
   __shared__ __attribute__((aligned(16))) half8 s[2 * 2 * GR_C * GR_ROW];  // 40 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -59,12 +86,13 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
       acc_hh[j][q] = 0.f;
       acc_x[j][q] = 0.f;
     }
+  const float t_scale = gram_t_scale(*absmax);
   const long total = (long)B * slabs_per_image;
   const long s_begin = (long)blockIdx.x * slabs_per_wg, s_end = (s_begin + slabs_per_wg < total) ? s_begin + slabs_per_wg : total;
   for (long sl = s_begin; sl < s_end; ++sl) {
     const long b = sl / slabs_per_image, p0 = (sl - b * slabs_per_image) * GR_PT;
     __syncthreads();  // the previous slab's fragments have been read
-    gram_stage(t, x, (size_t)b * GR_C * HW, HW, p0, s, tid);
+    gram_stage(t, x, (size_t)b * GR_C * HW, HW, p0, s, tid, t_scale);
     __syncthreads();
     // A = t rows of this wave's tile (channel 32 wave + r), B = x^2 rows of tile j; K step = 16 pixels = granules 2ks + h
 #pragma unroll
@@ -88,7 +116,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h, col = 32 * j + r;
-      out[row * GR_C + col] = (acc_hh[j][q] + acc_x[j][q] * (1.f / 2048.f)) * 256.f;
+      out[row * GR_C + col] = (acc_hh[j][q] + acc_x[j][q] * (1.f / 2048.f)) * (256.f / t_scale);
     }
 }
 
@@ -121,7 +149,12 @@ int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, flo
   const int per = (int)((slabs + parts - 1) / parts);
   const int grid = (int)((slabs + per - 1) / per);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(grid), dim3(256), 0, s, t, x, scratch, B, HW, spi, per);
+  unsigned int *absmax = reinterpret_cast<unsigned int *>(scratch + (size_t)parts * GR_C * GR_C);  // the scratch's last word
+  LICOS_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned int), s));
+  const long nt = (long)B * GR_C * HW;
+  hipLaunchKernelGGL(gram_absmax_kernel, dim3((int)((nt + 255) / 256 < 1024 ? (nt + 255) / 256 : 1024)), dim3(256), 0, s, t, nt, absmax);
+  LICOS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(grid), dim3(256), 0, s, t, x, scratch, absmax, B, HW, spi, per);
   LICOS_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(GR_C * GR_C / 256), dim3(256), 0, s, scratch, dgamma, grid);
   LICOS_LAUNCH_CHECK();

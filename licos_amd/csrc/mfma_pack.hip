@@ -73,6 +73,26 @@ __global__ void pack_deconv_w_fewch_kernel(const float *__restrict__ w, int Cin,
   }
 }
 
+// the same weights as v_mfma_f32_16x16x32_f16 A fragments for deconv5x5s2_few16_kernel: [chunk pair][tap][lane][8], lane
+// (row = lane % 16, k-group g = lane / 16) holding channels 32 pair + 16 (g / 2) + 8 (g % 2) + 0..7 of output channel `row`
+__global__ void pack_deconv_w_few16_kernel(const float *__restrict__ w, int Cin, int Cout, _Float16 *__restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const long tp = e >> 9;
+    const int T = (int)(tp % 25), pair = (int)(tp / 25);
+    const int row = lane & 15, g = lane >> 4;
+    const int phase = T < 9 ? 0 : T < 15 ? 1 : T < 21 ? 2 : 3;
+    const int tap0 = phase == 0 ? 0 : phase == 1 ? 9 : phase == 2 ? 15 : 21;
+    const int py = phase >> 1, px = phase & 1, nkx = px ? 2 : 3;
+    const int t = T - tap0;
+    const int ky = py + 2 * (t / nkx), kx = px + 2 * (t % nkx);
+    const int ci = 32 * pair + 16 * (g >> 1) + 8 * (g & 1) + j;
+    float v = 0.f;
+    if (row < Cout && ci < Cin) v = w[((size_t)ci * Cout + row) * 25 + ky * 5 + kx];
+    out[e] = (_Float16)v;
+  }
+}
+
 // GDN: gamma_eff = max(gamma, bound)^2 - pedestal as bf16 A-fragments, k-permuted for the
 // accumulator-as-B-operand product: element e of lane (r, h) of fragment (it, jt, s) is
 // gamma[32it + r][32jt + 16s + 8(e>>2) + 4h + (e&3)].  beta_eff (fp32, padded) follows.
@@ -253,12 +273,20 @@ static int fewch_rows(int Cout) { return Cout <= 4 ? 4 : Cout <= 8 ? 8 : Cout <=
 
 size_t licos_packed_deconv_w_fewch_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cout > 32) return 0;
+  if (fewch_uses_16x16x32(Cin, Cout)) return (size_t)(Cin / 32) * 25 * 1024;
   const int RP = fewch_rows(Cout), TPP = 32 / RP, WP = (25 + TPP - 1) / TPP;
   return (size_t)((Cin + 15) / 16) * WP * 1024;
 }
 
 int licos_pack_deconv_w_fewch_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
   LICOS_REQUIRE(w && packed && Cin > 0 && Cout > 0 && Cout <= 32, "pack_deconv_w_fewch_f16: unsupported Cin=%d Cout=%d", Cin, Cout);
+  if (fewch_uses_16x16x32(Cin, Cout)) {
+    const long total = (long)(Cin / 32) * 25 * 512;
+    hipLaunchKernelGGL(pack_deconv_w_few16_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,
+                       as_stream(stream), w, Cin, Cout, static_cast<_Float16 *>(packed), total);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   const int RP = fewch_rows(Cout), TPP = 32 / RP, WP = (25 + TPP - 1) / TPP, Cin16 = (Cin + 15) / 16;
   const long total = (long)Cin16 * WP * 512;
   hipLaunchKernelGGL(pack_deconv_w_fewch_kernel, dim3(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), dim3(256), 0,

@@ -128,11 +128,7 @@ template <int MT, int CC>
 static int launch_scatter_cc(const ScatterArgs &a, hipStream_t s) {
   const size_t lds = (size_t)MT * SC_OH * SC_OW * 4 + (size_t)MT * CC * 64 * 16;
   auto kern = deconv5x5s2_scatter_kernel<MT, CC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)a.tiles_x * a.tiles_y * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_scatter_f16: grid too large");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, a);

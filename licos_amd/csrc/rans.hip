@@ -739,11 +739,7 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
     dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
   }
   if (!indexes && n % plane == 0 && dec_lds <= 156 * 1024 && cdf_stride <= 65535) {
-    static size_t attr_lds = 0;
-    if (dec_lds > attr_lds) {
-      LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_plane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds));
-      attr_lds = dec_lds;
-    }
+    LICOS_ENSURE_LDS(rans_decode_plane_kernel, dec_lds);
     hipLaunchKernelGGL(rans_decode_plane_kernel, dim3(cdiv(B, 64 * cw)), dim3(64 * cw), dec_lds,
                        as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane, cdf, cdf_stride, cdf_len, offset,
                        symbols, status, B);

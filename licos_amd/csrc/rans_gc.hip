@@ -639,7 +639,7 @@ int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint3
   // 8-wave transform kernels, and the coders run beside the neighbouring chunk's transforms)
   auto launch = [&](auto kern, int waves) -> int {
     const size_t lds = (size_t)waves * ENC_DEPTH * ENC_BATCH * 64 * sizeof(uint4);
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LICOS_ENSURE_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), lds, as_stream(stream), static_cast<const uint4 *>(rec), aux, n,
                        words, cap_words, nwords, status, B);
     LICOS_LAUNCH_CHECK();
@@ -676,7 +676,7 @@ int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off, const vo
   const size_t lds = fixed + h.total_bytes;
   LICOS_REQUIRE(lds <= 160 * 1024, "rans_decode_image: image of %u bytes does not fit beside %d waves", h.total_bytes, waves);
   auto launch = [&](auto kern) -> int {
-    LICOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LICOS_ENSURE_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), lds, as_stream(stream), in, byte_off,
                        static_cast<const uint4 *>(idx16), n, static_cast<const uint4 *>(image), (int)h.total_bytes,
                        (int)h.off_meta, (int)h.off_rec, (int)h.off_cdf, symbols, sym_stride_b, sym_stride_i, status, B);

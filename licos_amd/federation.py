@@ -37,7 +37,10 @@ class FlatState:
             raise ValueError("no floating state to average")
         dev = tensors[0][1].device
         total = sum(v.numel() for _, v in tensors)
-        self.flat = torch.empty(total + 1, device=dev, dtype=torch.float32)
+        # the allocation is padded so that it splits into equal chunks for any power-of-two world up to 64 (the direct
+        # schedule ships one chunk per peer); `flat` is the live part: state + the coefficient element
+        self.alloc = torch.zeros(-(-(total + 1) // 64) * 64, device=dev, dtype=torch.float32)
+        self.flat = self.alloc[: total + 1]
         self.keys = []
         off = 0
         with torch.no_grad():
@@ -71,9 +74,11 @@ def reference_coefficients(losses, best_losses):
 
 class NativeComm:
     """An RCCL communicator owned by liblicos_hip.so (licos_comm_init): the collective of the federated average then
-    runs as ONE C-ABI call on the caller's stream (licos_allreduce_weighted: scale, all-reduce over xGMI, normalise)
-    instead of two kernels around torch.distributed's all_reduce.  The 128-byte id travels through the existing process
-    group (any backend).  Every rank of the group must construct it, with its device current."""
+    runs as ONE C-ABI call on the caller's stream (licos_allreduce_weighted: scale, all-reduce over xGMI, normalise;
+    licos_allreduce_weighted_direct: the two-step point-to-point schedule) instead of kernels around torch.distributed's
+    collectives.  The 128-byte id travels through the existing process group (any backend).  Every rank of the group
+    must construct it, with its device current.  A context manager: the communicator is destroyed on exit, also when the
+    body raises (a rank that dies inside leaves its peers in the collective - the launcher's job to end them)."""
 
     def __init__(self, group=None):
         lib = _lib.load()
@@ -87,6 +92,36 @@ class NativeComm:
         self._comm = ctypes.c_void_p()
         _lib.check(lib.licos_comm_init(ctypes.byref(self._comm), world, rank, ctypes.cast(ident, ctypes.c_void_p)), "comm_init")
         self.world, self.rank = world, rank
+        self._scratch = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def allreduce_weighted_direct_(self, flat_state, coef):
+        """The direct schedule on the FlatState's padded allocation."""
+        alloc, n = flat_state.alloc, flat_state.flat.numel()
+        ops._dev(alloc)
+        chunk = -(-n // self.world)
+        if chunk * self.world > alloc.numel():
+            raise ValueError(f"licos_amd: the direct schedule needs the bucket padded to {chunk * self.world} elements "
+                             f"({self.world} ranks); FlatState pads for power-of-two worlds up to 64")
+        if self._scratch is None or self._scratch.numel() < chunk * self.world or self._scratch.device != alloc.device:
+            self._scratch = torch.empty(chunk * self.world, device=alloc.device, dtype=torch.float32)
+        rc = _lib.load().licos_allreduce_weighted_direct(ops._p(alloc), n, alloc.numel(), float(coef), self._comm, self.world,
+                                                         self.rank, ops._p(self._scratch), ops._stream())
+        _lib.check(rc, "allreduce_weighted_direct")
+        ops.touch_weights()
+        return flat_state
 
     def allreduce_weighted_(self, flat, coef):
         ops._dev(flat)
@@ -101,13 +136,53 @@ class NativeComm:
             self._comm = ctypes.c_void_p()
 
 
-def weighted_average_(flat_state, coef, group=None, native=None):
-    """In place: bucket <- sum_r coef_r * bucket_r / sum_r coef_r over the process group (`native`: a NativeComm -
-    the whole step as one licos_allreduce_weighted call)."""
+def _direct_allreduce_(flat_state, group=None):
+    """SUM over the group on the direct schedule, through torch.distributed point-to-point operations (every backend
+    has them: RCCL for device tensors, gloo for the CPU rehearsal): rank r collects chunk r from every peer, adds them
+    in a fixed order, and hands the reduced chunk back to every peer - two exchange steps whatever the world size."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = flat_state.flat.numel()
+    chunk = -(-n // world)
+    alloc = flat_state.alloc
+    if chunk * world > alloc.numel():
+        raise ValueError(f"licos_amd: the direct schedule needs the bucket padded to {chunk * world} elements ({world} ranks)")
+    peers = [p for p in range(world) if p != rank]
+    gr = (lambda p: dist.get_global_rank(group, p)) if group is not None else (lambda p: p)
+    scratch = torch.empty((world, chunk), device=alloc.device, dtype=torch.float32)
+    view = alloc[: chunk * world].view(world, chunk)
+    ops1 = []
+    for p in peers:
+        ops1.append(dist.P2POp(dist.isend, view[p], gr(p), group))
+        ops1.append(dist.P2POp(dist.irecv, scratch[p], gr(p), group))
+    for w in dist.batch_isend_irecv(ops1):
+        w.wait()
+    for p in peers:  # ascending: the same order on every rank's own chunk
+        view[rank] += scratch[p]
+    ops2 = []
+    for p in peers:
+        ops2.append(dist.P2POp(dist.isend, view[rank], gr(p), group))
+        ops2.append(dist.P2POp(dist.irecv, view[p], gr(p), group))
+    for w in dist.batch_isend_irecv(ops2):
+        w.wait()
+    return flat_state
+
+
+SCHEDULES = ("ring", "direct")
+
+
+def weighted_average_(flat_state, coef, group=None, native=None, schedule="ring"):
+    """In place: bucket <- sum_r coef_r * bucket_r / sum_r coef_r over the process group.  `schedule`: "ring" = one
+    all-reduce (RCCL picks its algorithm), "direct" = the two-step point-to-point schedule of SURVEY 5.8 (xGMI is a
+    mesh of direct links).  `native`: a NativeComm - the whole step as one C-ABI call of liblicos_hip.so."""
+    if schedule not in SCHEDULES:
+        raise ValueError(f"schedule must be one of {SCHEDULES}")
     flat = flat_state.flat
     if native is not None:
         with torch.no_grad():
-            native.allreduce_weighted_(flat, coef)
+            if schedule == "direct":
+                native.allreduce_weighted_direct_(flat_state, coef)
+            else:
+                native.allreduce_weighted_(flat, coef)
         return flat_state
     with torch.no_grad():
         flat[-1] = 1.0
@@ -116,7 +191,10 @@ def weighted_average_(flat_state, coef, group=None, native=None):
         else:
             flat.mul_(coef)                    # gloo / CPU: only the collective logic is exercised here
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # "nccl" == RCCL over xGMI on ROCm
+            if schedule == "direct":
+                _direct_allreduce_(flat_state, group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # "nccl" == RCCL over xGMI on ROCm
         if flat.is_cuda:
             ops.scale_f32(flat[: flat_state.numel], 1.0, inv_alpha_dev=flat[flat_state.numel:])
         else:
@@ -137,7 +215,7 @@ def _gather_scalars(values, world, rank, device, group):
 
 
 def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_time, cfg=None, flat_state=None,
-                         group=None, uniform=False, native=None):
+                         group=None, uniform=False, native=None, schedule="ring"):
     """Collective counterpart of ``federation_utils.update_central_model`` (same leading arguments).
     Every rank of the group must call it.  Returns the FlatState (reuse it on the next call)."""
     if flat_state is None:
@@ -151,7 +229,7 @@ def update_central_model(rank, device, batch_idx, net, loss, best_loss, local_ti
         r = dist.get_rank(group)
         vals = _gather_scalars([loss, best_loss], world, r, flat_state.flat.device, group)
         coef = reference_coefficients(vals[:, 0].tolist(), vals[:, 1].tolist())[r]
-    weighted_average_(flat_state, coef, group=group, native=native)
+    weighted_average_(flat_state, coef, group=group, native=native, schedule=schedule)
     # the integer coder tables are functions of the (now averaged) parameters: rebuild them when the model carries any,
     # so that neither the module nor the checkpoint written below pairs new weights with old tables
     if any(getattr(m, "_offset", None) is not None and m._offset.numel() > 0 for m in net.modules()):

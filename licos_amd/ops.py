@@ -261,7 +261,8 @@ def conv2d_wgrad_f32(inp, g, ci, co, k, stride, pad, square_input=False):
     if GDN_MFMA and square_input and (k, stride, pad) == (1, 1, 0) and ci == co == 128 and (h * w) % 4 == 0:
         # the GDN gamma gradient: a 128 x 128 product over all pixels of the batch, on the matrix cores
         lib = _lib.load()
-        scratch = torch.empty(lib.licos_gdn_gamma_grad_parts(b, h * w) * 128 * 128, device=inp.device, dtype=torch.float32)
+        # partial matrices + one word for the kernel's max|t| pre-pass (licos_hip.h)
+        scratch = torch.empty(lib.licos_gdn_gamma_grad_parts(b, h * w) * 128 * 128 + 4, device=inp.device, dtype=torch.float32)
         dw = torch.empty((co, ci, 1, 1), device=inp.device, dtype=torch.float32)
         rc = lib.licos_gdn_gamma_grad_f32(_p(_f32(g.contiguous())), _p(_f32(inp.contiguous())), _p(scratch), _p(dw), b, 128, h * w, _stream())
         _lib.check(rc, "gdn_gamma_grad_f32")
@@ -412,6 +413,7 @@ def eb_likelihood(v, packed, filters, bound, form=0, sum_log2=None):
 
 def eb_likelihood_bwd(v, g_lik, packed, filters, bound, form=0):
     """(dL/dv, dL/dpacked-record [C][per_channel] w.r.t. the raw parameters) of eb_likelihood."""
+    g_lik = g_lik.contiguous()  # autograd may hand over an expanded (stride-0) gradient, e.g. for loss = lik.sum()
     _dev(v, g_lik, packed)
     b, c = v.shape[:2]
     hw = v[0, 0].numel()
@@ -426,6 +428,7 @@ def eb_likelihood_bwd(v, g_lik, packed, filters, bound, form=0):
 
 
 def gc_likelihood_bwd(v, scales, g_lik, scale_bound, lik_bound):
+    g_lik = g_lik.contiguous()
     _dev(v, scales, g_lik)
     dv, ds = torch.empty_like(v), torch.empty_like(v)
     rc = _lib.load().licos_gc_likelihood_bwd(_p(_f32(v)), _p(_f32(scales)), _p(_f32(g_lik.contiguous())), scale_bound, lik_bound,
@@ -436,6 +439,7 @@ def gc_likelihood_bwd(v, scales, g_lik, scale_bound, lik_bound):
 
 def mask_mul_f32(g, ref, mode):
     """g * (ref > 0) for mode "relu", g * sign(ref) for mode "abs"."""
+    g = g.contiguous()
     _dev(g, ref)
     out = torch.empty_like(g)
     rc = _lib.load().licos_mask_mul_f32(_p(_f32(g)), _p(_f32(ref)), _p(out), g.numel(), {"relu": 0, "abs": 1}[mode], _stream())
@@ -613,15 +617,26 @@ def rans_decode_image(data, byte_off, idx16, n, image_dev, image_host, symbols, 
 
 
 def host_threads():
-    """Worker threads for the host coder: this process's share of the box's cores (a GPU box gives one GPU 16)."""
+    """Worker threads for the host coder: this process's share of the cores it may run on.  With one process per GPU
+    the ranks of a node usually share one affinity mask (torchrun does not pin): the mask is divided by the node-local
+    world size (LOCAL_WORLD_SIZE from the launcher, else WORLD_SIZE), so 8 ranks on a 128-core host start 16 threads
+    each, not 8 x 16 on top of each other's cores.  Capped at 16: beyond that the per-call thread start-up outweighs
+    the work of the batches the host coder is chosen for.  LICOS_HOST_THREADS overrides."""
+    forced = os.environ.get("LICOS_HOST_THREADS")
+    if forced:
+        return max(1, int(forced))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(16, n))
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    except ValueError:
+        local_world = 1
+    return max(1, min(16, n // max(1, local_world)))
 
 
-# Coder placement (licos_amd/entropy_models.py): a GPU lane spends ~160 ns (encode) / ~330 ns (decode) per symbol of
+# Coder placement (licos_amd/entropy_models.py): a GPU lane spends ~160 ns (encode) / ~220 ns (decode) per symbol of
 # its stream whatever the batch, a host core ~5 / ~10 ns; with T host threads the host wins below ~32 T streams.
 # LICOS_HOST_CODER = "0" never, "1" always, otherwise automatic with this many streams per host thread as the limit.
 HOST_CODER = os.environ.get("LICOS_HOST_CODER", "auto")

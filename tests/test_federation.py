@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, losses, best, out, save_path=None):
+def _worker(rank, world, port, losses, best, out, save_path=None, schedule="ring"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, losses, best, out, save_path=None):
         net.load_state_dict(sd)
         before = {k: v.clone() for k, v in net.state_dict().items()}
         cfg = None if save_path is None else {"save_path": save_path, "save_checkpoints_over_time": True}
-        fs = federation.update_central_model(rank, "cpu", 5, net, losses[rank], best[rank], 12.5, cfg)
+        fs = federation.update_central_model(rank, "cpu", 5, net, losses[rank], best[rank], 12.5, cfg, schedule=schedule)
         assert federation.clock_sync(1) == world
         # parameters are views of the bucket: the module sees the averaged values without a load
         after = {k: v.clone() for k, v in net.state_dict().items()}
@@ -41,12 +41,14 @@ def _worker(rank, world, port, losses, best, out, save_path=None):
         dist.destroy_process_group()
 
 
-def test_weighted_allreduce_matches_sequential_blend(tmp_path):
-    world = 2
-    losses, best = [0.9, 0.6], [0.7, 0.6]
+@pytest.mark.parametrize("world,schedule", [(2, "ring"), (2, "direct"), (3, "direct")])
+def test_weighted_allreduce_matches_sequential_blend(tmp_path, world, schedule):
+    """Both schedules of the blend (one all-reduce; the two-step point-to-point exchange of SURVEY 5.8), world 2 and - for
+    the direct one, whose chunking depends on it - a world that does not divide the bucket."""
+    losses, best = [0.9, 0.6, 1.2][:world], [0.7, 0.6, 0.8][:world]
     out = str(tmp_path / "r{rank}.pt")
     save_path = str(tmp_path / "central_model")
-    mp.spawn(_worker, args=(world, _free_port(), losses, best, out, save_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), losses, best, out, save_path, schedule), nprocs=world, join=True)
     res = [torch.load(out.format(rank=r)) for r in range(world)]
     float_keys = [k for k, v in res[0]["before"].items() if v.dtype == torch.float32]
     ref = om.sequential_federation([{k: r["before"][k] for k in float_keys} for r in res], losses, best)
@@ -54,6 +56,7 @@ def test_weighted_allreduce_matches_sequential_blend(tmp_path):
     for r in res:
         for k in float_keys:
             assert torch.allclose(r["after"][k], ref[k], rtol=1e-5, atol=1e-7), k
+            assert torch.equal(r["after"][k], res[0]["after"][k]), k  # every rank holds the same bits
         for k, v in r["before"].items():
             if v.dtype != torch.float32:
                 assert torch.equal(r["after"][k], v)  # integer tables untouched

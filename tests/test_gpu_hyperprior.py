@@ -92,8 +92,9 @@ def test_hyperprior_fp32_stagewise(cin, size):
 
 
 def test_hyperprior_fp16_config5_size():
-    """BASELINE configs[4] shape: 13-band 512x512 tiles, g_a / g_s on the MFMA path (hyper transforms on the
-    fp32 kernels).  Rates and quality track the oracle; decode(encode(x)) is self-consistent."""
+    """BASELINE configs[4] shape: 13-band 512x512 tiles, all four transforms on the fp16 MFMA path (h_a / h_s: 3x3
+    stride-1 stages as one phase of the transposed-conv kernel, ReLU epilogues, |y| folded into the layout conversion).
+    Rates and quality track the oracle; decode(encode(x)) is self-consistent."""
     sd = _state(13, 7)
     net = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 1)
     net.load_state_dict(sd)

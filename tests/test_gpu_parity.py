@@ -117,6 +117,11 @@ def test_entropy_bottleneck_forward(cin):
         assert bool((d <= 1e-5 * ref_lik + 3e-7).all()), float(d.max())
         ref_s = torch.log2(ref_lik.double()).sum(dim=(1, 2, 3))
         assert torch.allclose(s.cpu(), ref_s, rtol=1e-5)
+        # the per-image totals do not depend on the order the workgroups' atomics arrive in: identical bits on re-runs
+        for _ in range(3):
+            s2 = torch.zeros(3, device=DEV, dtype=torch.float64)
+            eb(y.to(DEV), sum_log2=s2)
+            assert torch.equal(s2, s)
     # training mode with explicit noise
     nz = torch.rand(3, 192, 8, 8, generator=g) - 0.5
     eb.likelihood_form = "plain"
@@ -193,8 +198,10 @@ def test_model_golden_fp32(golden_dir, name):
     cin, form = int(g["in_channels"]), str(g["form"])
     sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=7)
     chk = float(sum(v.double().abs().sum() for k, v in sorted(sd.items()) if v.dtype.is_floating_point))
-    if abs(chk - float(g["state_checksum"])) > 1e-6 * abs(chk):
-        pytest.skip("torch RNG stream differs from the one the fixture was made with")
+    # the weights are re-drawn from torch's seeded generator, not stored: a torch whose RNG stream differs makes every
+    # number below meaningless - that is a FAILURE (regenerate with tests/golden/make_golden.py and commit), not a skip
+    assert abs(chk - float(g["state_checksum"])) <= 1e-6 * abs(chk), \
+        "torch's RNG stream differs from the one tests/golden/*.npz were made with: run tests/golden/make_golden.py"
     net = _load(cin, sd, form=form)
     eb = net.entropy_bottleneck
     if not np.array_equal(eb._quantized_cdf.cpu().numpy(), g["cdf"]):
@@ -218,19 +225,37 @@ def test_model_golden_fp32(golden_dir, name):
     sym = torch.from_numpy(sym.cpu().numpy().T.reshape(g["symbols"].shape).copy())
     med = sd["entropy_bottleneck.quantiles"][:, 0, 1]
     n_tie = tie_mismatches(sym, torch.from_numpy(g["y"]), med, tol=2e-5 * float(np.abs(g["y"]).max()))
-    if n_tie:
-        pytest.skip(f"{n_tie} latent(s) on a rounding tie on this host; covered stage-wise by the full-size test")
-    lik, ref = out["likelihoods"]["y"].cpu(), torch.from_numpy(g["lik"])
-    assert bool(((lik - ref).abs() <= 1e-5 * ref + 3e-7).all())
-    assert rel_err(out["x_hat"], torch.from_numpy(g["x_hat"])) < 1e-5
-    assert comp["strings"][0][0] == g["string0"].tobytes()
-    assert comp["strings"][0][1] == g["string1"].tobytes()
+    assert n_tie <= 4
     assert tuple(comp["shape"]) == (int(g["size"]) // 16,) * 2
-    assert rel_err(dec["x_hat"], torch.from_numpy(g["x_dec"])) < 1e-5
-    bpp = licos_amd.metrics.compute_bpp(out)
-    assert abs(bpp - float(g["bpp"])) < 1e-5 * float(g["bpp"])
-    psnr = licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x)
-    assert abs(psnr - float(g["psnr"])) < 1e-4
+    if n_tie == 0:
+        lik, ref = out["likelihoods"]["y"].cpu(), torch.from_numpy(g["lik"])
+        assert bool(((lik - ref).abs() <= 1e-5 * ref + 3e-7).all())
+        assert rel_err(out["x_hat"], torch.from_numpy(g["x_hat"])) < 1e-5
+        assert comp["strings"][0][0] == g["string0"].tobytes()
+        assert comp["strings"][0][1] == g["string1"].tobytes()
+        assert rel_err(dec["x_hat"], torch.from_numpy(g["x_dec"])) < 1e-5
+        bpp = licos_amd.metrics.compute_bpp(out)
+        assert abs(bpp - float(g["bpp"])) < 1e-5 * float(g["bpp"])
+        psnr = licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x)
+        assert abs(psnr - float(g["psnr"])) < 1e-4
+    else:
+        # a latent of this host's evaluation sits on a rounding tie and went the other way (two fp32 evaluations of g_a
+        # agree to ~1e-6): the stored bytes / reconstruction belong to the other symbol.  Everything downstream is then
+        # checked against the ORACLE run on the GPU's own symbols - same assertions, never a skip.
+        om.eb_update(sd, form=form)
+        cdf, cdf_len, offset = (sd["entropy_bottleneck." + k].numpy() for k in ("_quantized_cdf", "_cdf_length", "_offset"))
+        if not np.array_equal(cdf, g["cdf"]):
+            cdf, cdf_len, offset = g["cdf"], g["cdf_len"], g["offset"]
+        b, c, h, w = sym.shape
+        idx = np.repeat(np.arange(c, dtype=np.int32), h * w)
+        for i in range(b):
+            assert comp["strings"][0][i] == rans.encode_with_indexes(sym[i].reshape(-1).numpy().astype(np.int32), idx, cdf, cdf_len, offset)
+        y_hat = sym.float() + med.reshape(1, -1, 1, 1)
+        ref_x = om.g_s(y_hat, sd)
+        assert rel_err(out["x_hat"], ref_x) < 1e-5
+        assert rel_err(dec["x_hat"], ref_x.clamp(0, 1)) < 1e-5
+        ref_lik = om.eb_forward(y.cpu(), sd, form=form)[1]
+        assert bool(((out["likelihoods"]["y"].cpu() - ref_lik).abs() <= 1e-5 * ref_lik + 3e-7).all())
 
 
 @pytest.mark.parametrize("cin,kind", [(3, "aid"), (13, "s2-merged"), (1, "s2")])

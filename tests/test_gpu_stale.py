@@ -183,7 +183,7 @@ def test_forward_after_two_rank_weighted_average(tmp_path):
     assert rel_err(res[0]["after"]["g_a.2.weight"], res[0]["before"]["g_a.2.weight"]) > 1e-2
 
 
-def _native_worker(rank, world, port, out):
+def _native_worker(rank, world, port, out, schedule="ring"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -200,25 +200,65 @@ def _native_worker(rank, world, port, out):
             net.set_precision("fp16")
             y0 = net.g_a(x.to(DEV))
         before = _cpu_state(net)
-        comm = federation.NativeComm()
-        fs = federation.update_central_model(rank, DEV, 1, net, 0.8, 0.5, 0.0, native=comm)
-        with torch.no_grad():
-            y1 = net.g_a(x.to(DEV))
-        comm.close()
+        with federation.NativeComm() as comm:
+            fs = federation.update_central_model(rank, DEV, 1, net, 0.8, 0.5, 0.0, native=comm, schedule=schedule)
+            with torch.no_grad():
+                y1 = net.g_a(x.to(DEV))
+        assert not comm._comm  # destroyed on exit
         torch.save({"before": before, "after": _cpu_state(net), "coef": float(fs.flat[-1]), "dy": rel_err(y1, y0)}, out)
     finally:
         dist.destroy_process_group()
 
 
-def test_native_rccl_export_single_rank(tmp_path):
-    """licos_comm_* / licos_allreduce_weighted through a real RCCL communicator.  One GPU here, so one
-    rank: the all-reduce is the identity and the blend must return the model unchanged (to fp32 rounding of x * c / c),
-    with the coefficient in the bucket's last element and the caches invalidated.  More ranks: the driver's SCALE run
-    (bench.py reports `native_rccl`)."""
+@pytest.mark.parametrize("schedule", ["ring", "direct"])
+def test_native_rccl_export_single_rank(tmp_path, schedule):
+    """licos_comm_* / licos_allreduce_weighted(_direct) through a real RCCL communicator, both schedules.
+    One GPU here, so one rank: the exchange is the identity and the blend must return the model unchanged (to fp32
+    rounding of x * c / c), with the coefficient in the bucket's last element and the caches invalidated.  More ranks:
+    test_rccl_two_ranks_both_schedules below (needs two GPUs) and the driver's SCALE run (bench.py `fedavg_allreduce`)."""
     out = str(tmp_path / "n.pt")
-    mp.spawn(_native_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    mp.spawn(_native_worker, args=(1, _free_port(), out, schedule), nprocs=1, join=True)
     r = torch.load(out, weights_only=False)
     assert abs(r["coef"] - 1.0) < 1e-6 and r["dy"] < 1e-5
     for k, v in r["before"].items():
         if v.dtype == torch.float32:
             assert torch.allclose(r["after"][k], v, rtol=1e-6, atol=1e-12), k
+
+
+def _rccl_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        res = {}
+        with federation.NativeComm() as comm:
+            for name, kw in (("torch_ring", {}), ("torch_direct", {"schedule": "direct"}),
+                             ("native_ring", {"native": comm}), ("native_direct", {"native": comm, "schedule": "direct"})):
+                net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+                net.load_state_dict(om.perturb_state(om.make_factorized_state(3, 1, seed=rank), seed=rank))
+                net = net.to(dev).eval()
+                federation.update_central_model(rank, dev, 1, net, [0.9, 0.6][rank], [0.7, 0.6][rank], 0.0, **kw)
+                res[name] = {k: v.detach().cpu() for k, v in net.state_dict().items() if v.dtype == torch.float32}
+        torch.save(res, out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node (RCCL refuses two ranks on one device)")
+def test_rccl_two_ranks_both_schedules(tmp_path):
+    """The federated blend over RCCL with two ranks on two GPUs: torch.distributed and the library's own communicator,
+    ring and direct schedule - all four against the oracle's sequential blend, and identical on both ranks."""
+    out = str(tmp_path / "r{rank}.pt")
+    mp.spawn(_rccl_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = [torch.load(out.format(rank=r), weights_only=False) for r in range(2)]
+    states = [om.perturb_state(om.make_factorized_state(3, 1, seed=r), seed=r) for r in range(2)]
+    keys = list(res[0]["torch_ring"])
+    ref = om.sequential_federation([{k: s[k] for k in keys} for s in states], [0.9, 0.6], [0.7, 0.6])
+    for name in ("torch_ring", "torch_direct", "native_ring", "native_direct"):
+        for k in keys:
+            assert torch.allclose(res[0][name][k], ref[k].float(), rtol=1e-5, atol=1e-7), (name, k)
+            assert torch.equal(res[0][name][k], res[1][name][k]), (name, k)

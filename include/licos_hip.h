@@ -269,7 +269,9 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/
  *
  * licos_rans_image_build (host): turns the integer CDF table into the decoder image (meta, bucket records, 16-bit
  * symbol starts; licos_amd/csrc/rans_image.hpp) of at most budget_bytes (licos_rans_image_budget(waves) = what fits
- * in LDS beside the decode kernel's rings).  row_weight: optional expected use of each row (NULL = uniform).
+ * in LDS beside the decode kernel's rings).  row_weight: optional expected use of each row (NULL = uniform) - it only
+ * steers how the record budget is split between rows (a row used more gets finer buckets, so fewer values take the slow
+ * search); any weighting decodes every stream exactly.  licos_gc_decode_prepare can collect the statistic (row_hist).
  * licos_rans_image_lookup (host, test hook): symbol and [lo, hi) for a 16-bit value; returns 1 if the slow search ran.
  *
  * licos_gc_decode_prepare: scales [B][n] -> row bytes idx16 [ceil(n/16)][B][16].  licos_rans_decode_image: the serial
@@ -283,8 +285,9 @@ long licos_rans_image_budget(int waves);
 int licos_rans_image_build(const int32_t *cdf_host, const int32_t *cdf_len_host, const int32_t *offset_host, int rows, int stride,
                            const float *row_weight, long budget_bytes, void *image_out_host, long *image_bytes);
 int licos_rans_image_lookup(const void *image_host, int row, int cf, int32_t *symbol_lo_hi /*[3]*/);
-int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16, int B,
-                            long n, void *stream);
+int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16,
+                            unsigned int *row_hist /* optional uint32[256]: a sampled count of the rows in use, accumulated */,
+                            int B, long n, void *stream);
 int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const void *idx16, long n, const void *image,
                             const void *image_host_header, int32_t *symbols, long sym_stride_b, long sym_stride_i,
                             int32_t *status, int B, void *stream);

@@ -359,7 +359,9 @@ def decompress_hyper(net, strings, shape, chunk=512):
     from . import engine
     eb, gc = net.entropy_bottleneck, net.gaussian_conditional
     zcdf, zlen, zoff, _ = eb.coder_tables()
+    gc.note_row_usage()  # (nothing is in flight here) rows seen by earlier calls steer the image's record budget
     image_dev, image_host = gc.coder_image()
+    row_hist = gc.row_histogram()
     assert isinstance(strings, list) and len(strings) == 2
     ystrs, zstrs = strings
     B = len(ystrs)
@@ -403,7 +405,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
     for ci, ((s0, n), (data, off)) in enumerate(zip(pieces, yup)):
         side = _stream(dev, "coder%d" % (ci % CODER_STREAMS))
         scales = net.h_s(z_hat[s0:s0 + n])
-        idx16 = ops.gc_decode_prepare(scales.contiguous(), gc.scale_table, bound)
+        idx16 = ops.gc_decode_prepare(scales.contiguous(), gc.scale_table, bound, row_hist=row_hist)
         sym = torch.empty((ny, n), device=dev, dtype=torch.int32)
         ready = torch.cuda.Event()
         ready.record(main)

@@ -191,35 +191,44 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_kernel(const u
     for (int k = 0; k < ENC_BATCH; ++k) cur[k] = ring[((t & (ENC_DEPTH - 1)) * ENC_BATCH + k) * 64 + lane];
     if (t + ENC_AHEAD < nbat) request(t + ENC_AHEAD);
     const long i1 = n - t * ENC_BATCH;  // symbols i1 - 1 ... i1 - ENC_BATCH
+    // one symbol of the chain: renormalise (one word out when the state would overflow), divide by the reciprocal, add
+    auto code_symbol = [&](const uint4 r) {
+      const uint32_t cfreq = r.w & 0xFFFFu;  // 2^16 - freq
+      const uint32_t shift = (r.w >> 16) & 0x7FFFu;
+      const uint64_t rcp = ((uint64_t)r.y << 32) | r.x;
+      // x >= freq << 47  <=>  hi(x) >= (2^16 - cfreq) << 15  <=>  hi(x) + (cfreq << 15) >= 2^31   (hi(x) < 2^31)
+      const bool emit = (uint32_t)(x >> 32) + (cfreq << 15) >= 0x80000000u;
+      sink.put_if(emit, (uint32_t)x);
+      x = emit ? (x >> 32) : x;
+      const uint64_t q = __umul64hi(x, rcp) >> shift;
+      x = x + r.z + q * (uint64_t)cfreq;
+    };
+    auto code_escape = [&](const uint4 r, long i) {  // a value outside its row's range: bypass nibbles in front of the symbol
+      const uint32_t raw = (uint32_t)ap[(size_t)i * B];
+      int nbyp = 0;
+      while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+      // coding order is [symbol, count nibble, raw nibbles low -> high]; emitted reversed
+      for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+      put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+    };
     auto code_batch = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
+      // the escape flags of the whole batch are known up front (they ride in the records): a batch without any - nearly
+      // all of them - is ONE basic block of ENC_BATCH chained symbols, so the scheduler can fill the 8-cycle bubbles
+      // between dependent instructions with the neighbouring symbols' bookkeeping instead of stopping at a branch per symbol
+      uint32_t flags = 0;
+#pragma unroll
+      for (int k = 0; k < ENC_BATCH; ++k) flags |= cur[k].w;
+      if (FULL && __builtin_expect(!__any((flags & REC_ESCAPE) != 0), 1)) {
+#pragma unroll
+        for (int k = 0; k < ENC_BATCH; ++k) code_symbol(cur[k]);
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < ENC_BATCH; ++k) {
         if (!FULL && i1 - 1 - k < 0) break;
-        const bool escape = (cur[k].w & REC_ESCAPE) != 0;
-#if defined(LICOS_ABL) && LICOS_ABL == 12
-        if (false) {
-#else
-        if (__builtin_expect(__any(escape), 0)) {  // uniform and rare: some stream codes a value outside its row's range
-#endif
-          if (escape) {
-            const uint32_t raw = (uint32_t)ap[(size_t)(i1 - 1 - k) * B];
-            int nbyp = 0;
-            while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-            // coding order is [symbol, count nibble, raw nibbles low -> high]; emitted reversed
-            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
-            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
-          }
-        }
-        const uint32_t cfreq = cur[k].w & 0xFFFFu;  // 2^16 - freq
-        const uint32_t shift = (cur[k].w >> 16) & 0x7FFFu;
-        const uint64_t rcp = ((uint64_t)cur[k].y << 32) | cur[k].x;
-        // x >= freq << 47  <=>  hi(x) >= (2^16 - cfreq) << 15  <=>  hi(x) + (cfreq << 15) >= 2^31   (hi(x) < 2^31)
-        const bool emit = (uint32_t)(x >> 32) + (cfreq << 15) >= 0x80000000u;
-        sink.put_if(emit, (uint32_t)x);
-        x = emit ? (x >> 32) : x;
-        const uint64_t q = __umul64hi(x, rcp) >> shift;
-        x = x + cur[k].z + q * (uint64_t)cfreq;
+        if ((cur[k].w & REC_ESCAPE) != 0) code_escape(cur[k], i1 - 1 - k);
+        code_symbol(cur[k]);
       }
     };
     if (live) {
@@ -241,8 +250,12 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_kernel(const u
 // ---------------------------------------------------------------------------------------------- decode: prepare
 // scales -> row byte per symbol in granules of 16 positions: idx16[block][stream][16].  block = 64 streams x 64 positions.
 __global__ __launch_bounds__(256) void gc_decode_prepare_kernel(const float *__restrict__ scales, const float *__restrict__ table,
-                                                               int levels, float bound, uint4 *__restrict__ idx16, int B, long n) {
+                                                               int levels, float bound, uint4 *__restrict__ idx16,
+                                                               unsigned int *__restrict__ row_hist, int B, long n) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];
+  __shared__ unsigned int s_hist[256];
+  if (row_hist) s_hist[threadIdx.x] = 0;
+  if (row_hist) __syncthreads();
   const long i0 = (long)blockIdx.x * 64;
   const int b0 = blockIdx.y * 64;
   {
@@ -251,11 +264,15 @@ __global__ __launch_bounds__(256) void gc_decode_prepare_kernel(const float *__r
     for (int r = threadIdx.x >> 6; r < 64; r += 4) {
       const int b = b0 + r;
       int c = 0;
-      if (i < n && b < B) c = scale_row(scales[(size_t)b * n + i], table, levels, bound);
+      if (i < n && b < B) {
+        c = scale_row(scales[(size_t)b * n + i], table, levels, bound);
+        if (row_hist && ((p ^ r) & 7) == 0) atomicAdd(&s_hist[c], 1u);  // a 1-in-8 sample of the rows in use
+      }
       tile[r][p] = (uint8_t)c;
     }
   }
   __syncthreads();
+  if (row_hist && s_hist[threadIdx.x]) atomicAdd(&row_hist[threadIdx.x], s_hist[threadIdx.x]);
   {
     const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int b = b0 + r;
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   // 32-bit halves in the order the dependence chain runs.  Everything a rare event needs (bounded search in the row,
   // escape nibbles, ring refill) sits behind ONE wave-uniform branch.  `pack` / `offset`: the row's ImageMeta head.
 #ifdef LICOS_GC_STAMPS
-  long dbg_slow_n = 0, dbg_slow_cyc = 0, dbg_refill_cyc = 0, dbg_wait_cyc = 0;
+  long dbg_slow_n = 0, dbg_slow_cyc = 0, dbg_refill_cyc = 0, dbg_wait_cyc = 0, dbg_rb_n = 0, dbg_rb_cyc = 0, dbg_meta_cyc = 0, dbg_fast_cyc = 0;
   const long dbg_t0 = clock64();
 #endif
   auto step = [&](uint32_t row, uint32_t pack, int32_t offset) -> int32_t {
@@ -419,6 +436,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   };
 
   const long nfull = n / SYM_BLK;  // whole blocks; a ragged tail is decoded symbol by symbol at the end
+  int32_t *op = sp;                // where the next symbol of this stream goes (a running pointer: one 64-bit add per store)
   dma16(ip, s_idx);
   if (nblk > 1) dma16(ip + (size_t)B, s_idx + 64);
   for (long j = 0; j < nfull; ++j) {
@@ -436,30 +454,73 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
     dbg_wait_cyc += clock64() - sr1;
 #endif
     static_assert(SYM_BLK == 16, "the counted wait above is written for 16 stores per block");
-    const uint32_t *gp = reinterpret_cast<const uint32_t *>(s_idx + (j & (IDEPTH - 1)) * 64 + lane);
+    const uint4 g = s_idx[(j & (IDEPTH - 1)) * 64 + lane];
     if (j + 2 < nblk) dma16(ip + (size_t)(j + 2) * B, s_idx + ((j + 2) & (IDEPTH - 1)) * 64);
-    int32_t *op = sp + (size_t)(j * SYM_BLK) * ssi;
-    // four symbols per trip, NOT sixteen: unrolled further, the rare paths inlined behind every symbol push the loop
-    // past the 64 KB instruction cache and the hot path ends up waiting for its own code (measured: 245 -> ns/symbol)
-#pragma unroll 1
-    for (int q = 0; q < SYM_BLK / 4; ++q) {
-      const uint32_t gw = gp[q];
-      uint32_t pk[4];
-      int32_t of[4];
+    const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+    // The rows' metadata depends on the row bytes only: a quad's four reads are issued one quad AHEAD, so their LDS round
+    // trip (52 cycles per symbol when taken at the head of each quad: in-kernel stamps) runs under the previous quad's chain.
+    uint2 mm[2][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {  // the rows' metadata depends on the row bytes only: read off the state -> state chain
-        const uint2 mm = *reinterpret_cast<const uint2 *>(s_meta + ((gw >> (k * 8)) & 0xFFu));
-        pk[k] = mm.x;
-        of[k] = (int32_t)mm.y;
+    for (int k = 0; k < 4; ++k) mm[0][k] = *reinterpret_cast<const uint2 *>(s_meta + ((gw[0] >> (k * 8)) & 0xFFu));
+#pragma unroll
+    for (int q = 0; q < SYM_BLK / 4; ++q) {
+      if (q + 1 < SYM_BLK / 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mm[(q + 1) & 1][k] = *reinterpret_cast<const uint2 *>(s_meta + ((gw[q + 1] >> (k * 8)) & 0xFFu));
       }
       int32_t v[4];
+      // LICOS_GC_SPEC symbols at a time run SPECULATIVELY as one basic block - lookup, selects, multiply-add,
+      // renormalise, no branch: a branch per symbol costs ~120 of a step's ~290 cycles (in-kernel stamps: 170 cycles per
+      // symbol for the branch-free block).  A lane whose value fell outside its bucket's pair carries a wrong state from
+      // there on - harmlessly: every address it forms stays inside its tables - and is flagged; if any lane of the wave
+      // was, the state is restored and the group is redone symbol by symbol through the full step.  Pays once misses are
+      // rare (usage-weighted image: GaussianConditional.note_row_usage).
+#ifndef LICOS_GC_SPEC
+#define LICOS_GC_SPEC 2
+#endif
+      static_assert(LICOS_GC_SPEC == 0 || LICOS_GC_SPEC == 2 || LICOS_GC_SPEC == 4, "group of 0 (off), 2 or 4 symbols");
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = step((gw >> (k * 8)) & 0xFFu, pk[k], of[k]);
+      for (int k0 = 0; k0 < 4; k0 += (LICOS_GC_SPEC ? LICOS_GC_SPEC : 4)) {
+        if (LICOS_GC_SPEC == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = step((gw[q] >> (k * 8)) & 0xFFu, mm[q & 1][k].x, (int32_t)mm[q & 1][k].y);
+          continue;
+        }
+        const uint64_t x0 = x;
+        const int rd0 = src.rd;
+        bool missed = false;
+#pragma unroll
+        for (int k = k0; k < k0 + LICOS_GC_SPEC; ++k) {
+          const uint32_t pack = mm[q & 1][k].x;
+          const uint32_t x_lo = (uint32_t)x, x_hi = (uint32_t)(x >> 32);
+          const uint32_t cf = x_lo & 0xFFFFu;
+          const uint2 r = *reinterpret_cast<const uint2 *>(s_img + (pack >> IMAGE_PACK_SHIFT) + ((cf >> (pack & 31u)) << 3));
+          const uint32_t w_next = src.peek();
+          int s;
+          uint32_t off, freq;
+          bool miss;
+          image_pair(r, cf, s, off, freq, miss);
+          missed = missed || miss;
+          const uint32_t xs_lo = __builtin_amdgcn_alignbit(x_hi, x_lo, 16), xs_hi = x_hi >> 16;
+          uint64_t nx = (uint64_t)freq * xs_lo + off;
+          nx += (uint64_t)(freq * xs_hi) << 32;
+          const bool need = nx < RANS_L;
+          x = need ? ((nx << 32) | w_next) : nx;
+          src.rd += need ? 1 : 0;
+          v[k] = s + (int32_t)mm[q & 1][k].y;
+        }
+        if (__builtin_expect(__any(missed), 0)) {
+          x = x0;
+          src.rd = rd0;
+#pragma unroll
+          for (int k = k0; k < k0 + LICOS_GC_SPEC; ++k) v[k] = step((gw[q] >> (k * 8)) & 0xFFu, mm[q & 1][k].x, (int32_t)mm[q & 1][k].y);
+        }
+      }
       if (live) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          int32_t *a = op + (size_t)(q * 4 + k) * ssi;
-          asm volatile("global_store_dword %0, %1, off" ::"v"(a), "v"(v[k]) : "memory");
+          asm volatile("global_store_dword %0, %1, off" ::"v"(op), "v"(v[k]) : "memory");
+          op += ssi;
         }
       }
     }
@@ -478,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
 #ifdef LICOS_GC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     long *d = reinterpret_cast<long *>(status + 2);
-    d[0] = clock64() - dbg_t0; d[1] = dbg_slow_n; d[2] = dbg_slow_cyc; d[3] = dbg_refill_cyc; d[4] = dbg_wait_cyc;
+    d[0] = clock64() - dbg_t0; d[1] = dbg_slow_n; d[2] = dbg_slow_cyc; d[3] = dbg_refill_cyc; d[4] = dbg_wait_cyc; d[5] = dbg_rb_n; d[6] = dbg_rb_cyc; d[7] = dbg_meta_cyc; d[8] = dbg_fast_cyc;
   }
 #endif
   if (live && (src.over || src.rd > src.nw)) atomicOr(status, 1);  // words past a stream's end read as zeros; flagged here
@@ -648,12 +709,12 @@ int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint3
   return B > 64 ? launch(rans_encode_records_kernel<2>, 2) : launch(rans_encode_records_kernel<1>, 1);
 }
 
-int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16, int B,
-                            long n, void *stream) {
+int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16,
+                            unsigned int *row_hist, int B, long n, void *stream) {
   LICOS_REQUIRE(scales && scale_table && idx16 && levels > 0 && levels <= 256 && B > 0 && n > 0, "gc_decode_prepare: bad arguments");
   LICOS_REQUIRE((n + 63) / 64 < (1L << 31) && (B + 63) / 64 < 65536, "gc_decode_prepare: too many symbols or streams");
   hipLaunchKernelGGL(gc_decode_prepare_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((B + 63) / 64)), dim3(256), 0,
-                     as_stream(stream), scales, scale_table, levels, scale_bound, static_cast<uint4 *>(idx16), B, n);
+                     as_stream(stream), scales, scale_table, levels, scale_bound, static_cast<uint4 *>(idx16), row_hist, B, n);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -439,19 +439,68 @@ class GaussianConditional(nn.Module):
     coder_tables = EntropyBottleneck.coder_tables
     coder_tables_host = EntropyBottleneck.coder_tables_host
 
+    # ---- decoder image (licos_rans_image_build): how the LDS record budget is split between the table rows ----------
+    # A row's buckets resolve a value in one 8-byte read unless it falls outside the bucket's best pair of symbols; the
+    # fewer buckets a row has, the more often that happens (the slow, still exact, search).  Which rows matter depends on
+    # the DATA: a trained hyperprior predicts sigma < 0.2 for most elements and a band of mid scales for the rest.  The
+    # image therefore starts from a prior (rows of sigma <= ~14 weigh 1, wider ones 0.05) and follows the observed use:
+    # licos_gc_decode_prepare samples a histogram of the rows it emits, `note_row_usage` folds it into a running
+    # average between calls, and the image is rebuilt (3 ms on the host) when the average has drifted.
+    _PRIOR_SPLIT, _PRIOR_TAIL, _USAGE_DRIFT = 40, 0.05, 0.12
+
+    def _row_weight(self, rows):
+        w = np.where(np.arange(rows) <= self._PRIOR_SPLIT, 1.0, self._PRIOR_TAIL).astype(np.float32)
+        usage = getattr(self, "_row_usage", None)
+        if usage is not None and usage.size == rows:
+            w = (0.02 * w / w.sum() + usage / max(float(usage.sum()), 1e-30)).astype(np.float32)  # never starve a row entirely
+        return w
+
+    def row_histogram(self):
+        """int32 [256] on the tables' device: handed to ops.gc_decode_prepare, read back by note_row_usage()."""
+        dev = self._quantized_cdf.device
+        h = getattr(self, "_row_hist", None)
+        if h is None or h.device != dev:
+            h = self._row_hist = torch.zeros(256, device=dev, dtype=torch.int32)
+        return h
+
+    def note_row_usage(self):
+        """Fold the histogram collected since the last call into the running row usage (one tiny D2H; call it between
+        codec calls, when nothing is in flight).  Returns True when the image will be rebuilt."""
+        h = getattr(self, "_row_hist", None)
+        if h is None:
+            return False
+        counts = h.cpu().numpy().astype(np.float64)
+        total = counts.sum()
+        if total < 4096:
+            return False
+        h.zero_()
+        rows = int(self._quantized_cdf.shape[0])
+        p = counts[:rows] / total
+        old = getattr(self, "_row_usage", None)
+        self._row_usage = p if old is None or old.size != rows else 0.5 * old + 0.5 * p
+        built = getattr(self, "_image_usage", None)
+        if built is None or built.size != rows or float(np.abs(built - self._row_usage).sum()) > self._USAGE_DRIFT:
+            self._image_for = None  # rebuilt by the next coder_image()
+            return True
+        return False
+
     def coder_image(self):
         """(device blob, host blob) of the decoder image the scale-conditioned fast path keeps in LDS
-        (licos_rans_image_build; rebuilt with the coder tables), or None when the tables do not fit one."""
+        (licos_rans_image_build; rebuilt with the coder tables or when the observed row usage has drifted), or None when
+        the tables do not fit one."""
         tables = self.coder_tables()
         if getattr(self, "_image_for", None) is not tables:  # (the tuple is rebuilt whenever the tables are)
             cdf_h, len_h, off_h, _ = self._coder_host
             try:
-                blob = ops.rans_image_build(cdf_h, len_h, off_h) if cdf_h.shape[0] <= 256 else None
+                blob = ops.rans_image_build(cdf_h, len_h, off_h, row_weight=self._row_weight(cdf_h.shape[0])) if cdf_h.shape[0] <= 256 else None
             except ValueError:
                 blob = None
             self._image = None if blob is None else (torch.from_numpy(blob).to(self._quantized_cdf.device), blob)
             self._image_for = tables
+            usage = getattr(self, "_row_usage", None)
+            self._image_usage = None if usage is None else usage.copy()
         return self._image
+
     _check_cdfs = EntropyBottleneck._check_cdfs
     _compress_host = EntropyBottleneck._compress_host
     _decompress_host = EntropyBottleneck._decompress_host

@@ -593,14 +593,15 @@ def rans_encode_records(rec, aux, cap_words):
     return words[1:], nwords, status
 
 
-def gc_decode_prepare(scales, scale_table, scale_bound):
-    """Row byte per symbol in the decoder's granule layout: uint8 [ceil(n/16)][B][16]."""
-    _dev(scales, scale_table)
+def gc_decode_prepare(scales, scale_table, scale_bound, row_hist=None):
+    """Row byte per symbol in the decoder's granule layout: uint8 [ceil(n/16)][B][16].  `row_hist` (int32 [256] on the
+    device, optional) accumulates a sampled histogram of the rows in use."""
+    _dev(scales, scale_table, row_hist)
     b = scales.shape[0]
     n = scales[0].numel()
     idx16 = torch.empty(((n + 15) // 16, b, 16), device=scales.device, dtype=torch.uint8)
-    rc = _lib.load().licos_gc_decode_prepare(_p(_f32(scales)), _p(_f32(scale_table)), scale_table.numel(), scale_bound, _p(idx16), b, n,
-                                             _stream())
+    rc = _lib.load().licos_gc_decode_prepare(_p(_f32(scales)), _p(_f32(scale_table)), scale_table.numel(), scale_bound, _p(idx16),
+                                             _p(row_hist), b, n, _stream())
     _lib.check(rc, "gc_decode_prepare")
     return idx16
 

@@ -49,14 +49,21 @@ off = np.zeros(B + 1, dtype=np.int64)
 np.cumsum(host * 4, out=off[1:])
 off_dev = torch.from_numpy(off).to(dev)
 data = ops.rans_compact(words, nwords, off_dev, int(off[-1]))
-idx16 = ops.gc_decode_prepare(scales, gc.scale_table, bound)
+idx16 = ops.gc_decode_prepare(scales, gc.scale_table, bound, row_hist=gc.row_histogram())
 sym = torch.empty((n, B), device=dev, dtype=torch.int32)
-dbg = torch.zeros(16, device=dev, dtype=torch.int32)
+ms_prior, _ = timed(lambda: ops.rans_decode_image(data, off_dev, idx16, n, image_dev, image_host, sym, 1, B, B))
+rebuilt = gc.note_row_usage()  # the rows this data uses now steer the image's record budget
+image_dev, image_host = gc.coder_image()
+print("decode with the prior-weighted image: %.2f ms = %.1f ns/symbol; image rebuilt from the observed rows: %s" % (ms_prior, 1e6 * ms_prior / n, rebuilt))
+dbg = torch.zeros(32, device=dev, dtype=torch.int32)
 ms_d, st = timed(lambda: ops.rans_decode_image(data, off_dev, idx16, n, image_dev, image_host, sym, 1, B, B, status=dbg))
-d = dbg[2:12].cpu().view(torch.int64).tolist()
+d = dbg[2:22].cpu().view(torch.int64).tolist()
 if d[0]:
     print("decode stamps (wave 0): total %d cycles = %.1f per symbol; slow path entered %d times (%.2f%% of symbols), %.1f cycles each = %.1f per symbol; "
-          "refill checks %.1f, vmcnt waits %.1f cycles per symbol" % (d[0], d[0] / n, d[1], 100.0 * d[1] / n, d[2] / max(d[1], 1), d[2] / n, d[3] / n, d[4] / n))
+          "refill checks %.1f, vmcnt waits %.1f cycles per symbol; quads rolled back %d (%.1f%%), %.0f cycles each = %.1f per symbol"
+          % (d[0], d[0] / n, d[1], 100.0 * d[1] / n, d[2] / max(d[1], 1), d[2] / n, d[3] / n, d[4] / n, d[5], 400.0 * d[5] / n,
+             d[6] / max(d[5], 1), d[6] / n))
+    print("   per symbol: metadata phase %.1f, speculative quad %.1f cycles" % (d[7] / n, d[8] / n))
 ok = bool(torch.equal(sym.t().reshape(B, 192, 32, 32), torch.round(y).int()))
 print("streams %d x %d symbols: encode %.2f ms = %.1f ns/symbol, decode %.2f ms = %.1f ns/symbol, %.3f bits/symbol, round trip %s"
       % (B, n, ms_e, 1e6 * ms_e / n, ms_d, 1e6 * ms_d / n, 8.0 * off[-1] / (B * n), "ok" if ok else "MISMATCH"))

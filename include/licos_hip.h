@@ -288,9 +288,15 @@ int licos_rans_image_lookup(const void *image_host, int row, int cf, int32_t *sy
 int licos_gc_decode_prepare(const float *scales, const float *scale_table, int levels, float scale_bound, void *idx16,
                             unsigned int *row_hist /* optional uint32[256]: a sampled count of the rows in use, accumulated */,
                             int B, long n, void *stream);
-int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const void *idx16, long n, const void *image,
-                            const void *image_host_header, int32_t *symbols, long sym_stride_b, long sym_stride_i,
-                            int32_t *status, int B, void *stream);
+int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const void *idx16,
+                            int rows_shared /* 1: idx16 is [ceil(n/16)][16], the same rows for every stream */, long n,
+                            const void *image, const void *image_host_header, int32_t *symbols, long sym_stride_b,
+                            long sym_stride_i, int32_t *status, int B, void *stream);
+/* The same record encoder for the ENTROPY BOTTLENECK ([CAI] EntropyBottleneck.compress: row = channel of the element,
+ * symbol = round(y - median[channel])): y [B][C][plane] fp32 -> rec / aux as above; decode with licos_rans_decode_image,
+ * rows_shared = 1 and the channel pattern as idx16 (C <= 256). */
+int licos_eb_encode_prepare(const float *y, const float *medians, int C, int plane, const void *enc_table, int cdf_stride,
+                            const int32_t *cdf_len, const int32_t *offset, void *rec, int32_t *aux, int B, void *stream);
 
 /* ------------------------------------------------------- federated averaging
  * Replaces the file-based pair-wise blend of /root/reference/licos/federation_utils.py:47-53 by one

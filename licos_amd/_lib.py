@@ -53,7 +53,8 @@ SIGNATURES = {
     "licos_rans_image_build": (_i, [_vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp]),
     "licos_rans_image_lookup": (_i, [_vp, _i, _i, _vp]),
     "licos_gc_decode_prepare": (_i, [_vp, _vp, _i, _f, _vp, _vp, _i, _l, _vp]),
-    "licos_rans_decode_image": (_i, [_vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _l, _vp, _i, _vp]),
+    "licos_rans_decode_image": (_i, [_vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _l, _l, _vp, _i, _vp]),
+    "licos_eb_encode_prepare": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "licos_gc_likelihood": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
     "licos_gc_build_indexes": (_i, [_vp, _vp, _i, _f, _vp, _l, _l, _i, _l, _vp]),
     "licos_dn12_to_grid8_f32": (_i, [_vp, _vp, _l, _i, _vp]),

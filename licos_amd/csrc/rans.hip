@@ -212,20 +212,7 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
           rec[k] = s_tab[value];
         }
       }
-#pragma unroll
-      for (int k = 0; k < SYM_BATCH; ++k) {
-        if (!FULL && k >= nb) break;
-        const int32_t value = sv[k] - off;
-        const bool escape = value < 0 || value >= max_value;
-        if (__builtin_expect(__any(escape), 0)) {  // uniform and rare: some stream codes an out-of-range value
-          if (escape) {
-            const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
-            int nbyp = 0;
-            while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
-            for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
-            put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
-          }
-        }
+      auto code_symbol = [&](int k) {
         // straight-line renormalise + encode: x >= freq << 47 compares the high words (the low 47 bits of the bound are 0)
         const uint32_t freq = rec[k].freq ? rec[k].freq : 65536u;
         const bool emit = (uint32_t)(x >> 32) >= (freq << 15);
@@ -233,6 +220,33 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
         x = emit ? (x >> 32) : x;
         const uint64_t q = __umul64hi(x, rec[k].rcp) >> rec[k].shift;
         x = x + rec[k].bias + q * (uint64_t)(65536u - freq);
+      };
+      // whether any symbol of the batch is out of its channel's range is known before the chain starts: a batch without
+      // escapes - nearly all of them - is ONE basic block of SYM_BATCH chained symbols, so the scheduler can fill the
+      // 8-cycle bubbles between dependent instructions with the neighbours' bookkeeping (a branch per symbol ends the block)
+      bool any_escape = false;
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k) {
+        const int32_t value = sv[k] - off;
+        any_escape = any_escape || ((FULL || k < nb) && (value < 0 || value >= max_value));
+      }
+      if (FULL && __builtin_expect(!__any(any_escape), 1)) {
+#pragma unroll
+        for (int k = 0; k < SYM_BATCH; ++k) code_symbol(k);
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < SYM_BATCH; ++k) {
+        if (!FULL && k >= nb) break;
+        const int32_t value = sv[k] - off;
+        if (value < 0 || value >= max_value) {  // rare: this stream codes an out-of-range value
+          const uint32_t raw = (value < 0) ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
+          int nbyp = 0;
+          while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+          for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+          put_bits4(x, sink, (uint32_t)nbyp);  // nbyp <= 8 < 15: a single count nibble
+        }
+        code_symbol(k);
       }
     };
     fetch(plane, sv_next);

@@ -48,6 +48,9 @@ __device__ inline int scale_row(float s, const float *__restrict__ table, int le
 
 // block = 64 streams x 32 positions; latents and scales are read along positions (NCHW rows), records leave along
 // streams (the coder's lanes), through LDS
+// BY_SCALE: the row of an element is chosen by its predicted scale (GaussianConditional); otherwise it is the element's
+// channel, position / plane, and the symbol is round(y - median[channel]) (EntropyBottleneck: `scales` = the medians).
+template <bool BY_SCALE>
 __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__restrict__ y, const float *__restrict__ scales,
                                                                const float *__restrict__ table, int levels, float bound,
                                                                const uint4 *__restrict__ enc_table, int cdf_stride,
@@ -67,9 +70,10 @@ __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__r
       int32_t raw = 0;
       if (i < n && b < B) {
         const size_t at = (size_t)b * n + i;
-        const int c = scale_row(scales[at], table, levels, bound);
+        const int c = BY_SCALE ? scale_row(scales[at], table, levels, bound) : (int)(i / levels);  // (`levels` = the plane size)
         const int32_t max_value = cdf_len[c] - 2;
-        int32_t v = (int32_t)rintf(y[at]) - offset[c];  // round-half-to-even, as torch.round
+        const float centred = BY_SCALE ? y[at] : y[at] - scales[c];
+        int32_t v = (int32_t)rintf(centred) - offset[c];  // round-half-to-even, as torch.round
         bool esc = false;
         if (v < 0) { raw = -2 * v - 1; v = max_value; esc = true; }
         else if (v >= max_value) { raw = 2 * (v - max_value); v = max_value; esc = true; }
@@ -337,7 +341,7 @@ __device__ __forceinline__ uint32_t get_bits4(uint64_t &x, RingSource &src) {
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uint8_t *__restrict__ in,
                                                                        const int64_t *__restrict__ byte_off,
-                                                                       const uint4 *__restrict__ idx16, long n,
+                                                                       const uint4 *__restrict__ idx16, int rows_shared, long n,
                                                                        const uint4 *__restrict__ image, int image_bytes,
                                                                        int off_meta, int off_rec, int off_cdf,
                                                                        int32_t *__restrict__ symbols, long ssb, long ssi,
@@ -363,7 +367,10 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   x |= (uint64_t)src.next() << 32;
   int32_t *sp = symbols + (size_t)b * ssb;
   const long nblk = (n + SYM_BLK - 1) / SYM_BLK;
-  const uint4 *ip = idx16 + b;  // granule of block j at ip[j * B]
+  // granule of block j at ip[j * gstride]; rows_shared: every stream walks the same rows (one granule per block: the
+  // entropy bottleneck's channel pattern), all lanes then fetch the same 16 bytes
+  const uint4 *ip = idx16 + (rows_shared ? 0 : b);
+  const size_t gstride = rows_shared ? 1 : (size_t)B;
   // Row-index granules travel global -> LDS two blocks ahead.  vmcnt discipline of a block j (all vector-memory
   // operations of the loop are issued by this code, in this order):
   //     wait for granule j | read it | request granule j + 2 | SYM_BLK symbols | SYM_BLK stores
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   const long nfull = n / SYM_BLK;  // whole blocks; a ragged tail is decoded symbol by symbol at the end
   int32_t *op = sp;                // where the next symbol of this stream goes (a running pointer: one 64-bit add per store)
   dma16(ip, s_idx);
-  if (nblk > 1) dma16(ip + (size_t)B, s_idx + 64);
+  if (nblk > 1) dma16(ip + gstride, s_idx + 64);
   for (long j = 0; j < nfull; ++j) {
 #ifdef LICOS_GC_STAMPS
     const long sr0 = clock64();
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
 #endif
     static_assert(SYM_BLK == 16, "the counted wait above is written for 16 stores per block");
     const uint4 g = s_idx[(j & (IDEPTH - 1)) * 64 + lane];
-    if (j + 2 < nblk) dma16(ip + (size_t)(j + 2) * B, s_idx + ((j + 2) & (IDEPTH - 1)) * 64);
+    if (j + 2 < nblk) dma16(ip + (size_t)(j + 2) * gstride, s_idx + ((j + 2) & (IDEPTH - 1)) * 64);
     const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
     // The rows' metadata depends on the row bytes only: a quad's four reads are issued one quad AHEAD, so their LDS round
     // trip (52 cycles per symbol when taken at the head of each quad: in-kernel stamps) runs under the previous quad's chain.
@@ -685,9 +692,22 @@ int licos_gc_encode_prepare(const float *y, const float *scales, const float *sc
   LICOS_REQUIRE(y && scales && scale_table && enc_table && cdf_len && offset && rec && aux, "gc_encode_prepare: NULL buffer");
   LICOS_REQUIRE(levels > 0 && levels <= 256 && B > 0 && n > 0 && cdf_stride > 1, "gc_encode_prepare: bad sizes");
   LICOS_REQUIRE((n + 31) / 32 < (1L << 31) && (B + 63) / 64 < 65536, "gc_encode_prepare: too many symbols or streams");
-  hipLaunchKernelGGL(gc_encode_prepare_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((B + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(gc_encode_prepare_kernel<true>, dim3((unsigned)((n + 31) / 32), (unsigned)((B + 63) / 64)), dim3(256), 0,
                      as_stream(stream), y, scales, scale_table, levels, scale_bound, static_cast<const uint4 *>(enc_table),
                      cdf_stride, cdf_len, offset, static_cast<uint4 *>(rec), aux, B, n);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_encode_prepare(const float *y, const float *medians, int C, int plane, const void *enc_table, int cdf_stride,
+                            const int32_t *cdf_len, const int32_t *offset, void *rec, int32_t *aux, int B, void *stream) {
+  LICOS_REQUIRE(y && medians && enc_table && cdf_len && offset && rec && aux, "eb_encode_prepare: NULL buffer");
+  LICOS_REQUIRE(C > 0 && plane > 0 && B > 0 && cdf_stride > 1, "eb_encode_prepare: bad sizes");
+  const long n = (long)C * plane;
+  LICOS_REQUIRE((n + 31) / 32 < (1L << 31) && (B + 63) / 64 < 65536, "eb_encode_prepare: too many symbols or streams");
+  hipLaunchKernelGGL(gc_encode_prepare_kernel<false>, dim3((unsigned)((n + 31) / 32), (unsigned)((B + 63) / 64)), dim3(256), 0,
+                     as_stream(stream), y, medians, nullptr, plane, 0.f, static_cast<const uint4 *>(enc_table), cdf_stride, cdf_len,
+                     offset, static_cast<uint4 *>(rec), aux, B, n);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
@@ -724,9 +744,9 @@ long licos_rans_image_budget(int waves) {
   return 160L * 1024 - 256 - (long)waves * (RING * 64 * 4 + IDEPTH * 64 * 16);
 }
 
-int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off, const void *idx16, long n, const void *image,
-                            const void *image_host_header, int32_t *symbols, long sym_stride_b, long sym_stride_i,
-                            int32_t *status, int B, void *stream) {
+int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off, const void *idx16, int rows_shared, long n,
+                            const void *image, const void *image_host_header, int32_t *symbols, long sym_stride_b,
+                            long sym_stride_i, int32_t *status, int B, void *stream) {
   LICOS_REQUIRE(in && byte_off && idx16 && image && image_host_header && symbols && status && B > 0 && n > 0, "rans_decode_image: bad arguments");
   LICOS_REQUIRE(((uintptr_t)in & 3) == 0 && ((uintptr_t)image & 15) == 0, "rans_decode_image: misaligned input");
   ImageHeader h;
@@ -739,7 +759,7 @@ int licos_rans_decode_image(const uint8_t *in, const int64_t *byte_off, const vo
   auto launch = [&](auto kern) -> int {
     LICOS_ENSURE_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), lds, as_stream(stream), in, byte_off,
-                       static_cast<const uint4 *>(idx16), n, static_cast<const uint4 *>(image), (int)h.total_bytes,
+                       static_cast<const uint4 *>(idx16), rows_shared, n, static_cast<const uint4 *>(image), (int)h.total_bytes,
                        (int)h.off_meta, (int)h.off_rec, (int)h.off_cdf, symbols, sym_stride_b, sym_stride_i, status, B);
     LICOS_LAUNCH_CHECK();
     return LICOS_OK;

@@ -205,6 +205,34 @@ class EntropyBottleneck(nn.Module):
         self.coder_tables()
         return self._coder_host
 
+    def coder_image(self):
+        """(device blob, host blob) of the decoder image of this model's per-channel tables for the record / image coder
+        (licos_rans_image_build: csrc/rans_gc.hip serves the entropy bottleneck too - row = channel), or None when it
+        does not apply (more than 256 channels, tables too large for LDS)."""
+        tables = self.coder_tables()
+        if getattr(self, "_image_for", None) is not tables:
+            cdf_h, len_h, off_h, _ = self._coder_host
+            blob = None
+            if cdf_h.shape[0] <= 256 and int(len_h.min()) >= 3:
+                try:
+                    blob = ops.rans_image_build(cdf_h, len_h, off_h)
+                except ValueError:
+                    blob = None
+            self._image = None if blob is None else (torch.from_numpy(blob).to(self._quantized_cdf.device), blob)
+            self._image_for = tables
+        return self._image
+
+    def channel_rows(self, plane):
+        """The row (= channel) of every position of a stream as the decoder's shared granules: uint8 [ceil(n/16)][16]."""
+        c = int(self._quantized_cdf.shape[0])
+        key = (c, int(plane), str(self._quantized_cdf.device))
+        if getattr(self, "_rows_key", None) != key:
+            rows = np.repeat(np.arange(c, dtype=np.uint8), plane)
+            rows = np.concatenate((rows, np.zeros((-rows.size) % 16, dtype=np.uint8)))
+            self._rows = torch.from_numpy(rows.reshape(-1, 16)).to(self._quantized_cdf.device)
+            self._rows_key = key
+        return self._rows
+
     # ------------------------------------------------------------------ device path
     def packed_params(self):
         key = (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in

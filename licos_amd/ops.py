@@ -606,13 +606,28 @@ def gc_decode_prepare(scales, scale_table, scale_bound, row_hist=None):
     return idx16
 
 
+def eb_encode_prepare(y, medians, enc_table, cdf_len, offset, cdf_stride):
+    """Entropy-bottleneck latents y (B, C, *spatial) -> (rec [n][B][4] int32, aux [n][B]) for rans_encode_records."""
+    _dev(y, medians, enc_table, cdf_len, offset)
+    b, c = y.shape[:2]
+    plane = y[0, 0].numel()
+    n = c * plane
+    rec = torch.empty((n, b, 4), device=y.device, dtype=torch.int32)
+    aux = torch.empty((n, b), device=y.device, dtype=torch.int32)
+    rc = _lib.load().licos_eb_encode_prepare(_p(_f32(y)), _p(_f32(medians)), c, plane, _p(enc_table), cdf_stride, _p(cdf_len), _p(offset),
+                                             _p(rec), _p(aux), b, _stream())
+    _lib.check(rc, "eb_encode_prepare")
+    return rec, aux
+
+
 def rans_decode_image(data, byte_off, idx16, n, image_dev, image_host, symbols, sym_stride_b, sym_stride_i, batch, status=None,
-                      sym_offset=0):
+                      sym_offset=0, rows_shared=False):
     _dev(data, byte_off, idx16, image_dev, symbols)
     if status is None:
         status = torch.zeros(1, device=data.device, dtype=torch.int32)
-    rc = _lib.load().licos_rans_decode_image(_p(data), _p(byte_off), _p(idx16), n, _p(image_dev), ctypes.c_void_p(image_host.ctypes.data),
-                                             _p_off(symbols, sym_offset), sym_stride_b, sym_stride_i, _p(status), batch, _stream())
+    rc = _lib.load().licos_rans_decode_image(_p(data), _p(byte_off), _p(idx16), int(bool(rows_shared)), n, _p(image_dev),
+                                             ctypes.c_void_p(image_host.ctypes.data), _p_off(symbols, sym_offset), sym_stride_b,
+                                             sym_stride_i, _p(status), batch, _stream())
     _lib.check(rc, "rans_decode_image")
     return status
 

@@ -223,8 +223,8 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             if host_t is not None:
                 data = host_t[: max(int(off[-1]), 4)].to(dev, non_blocking=True)
                 byte_off = torch.from_numpy(off).to(dev, non_blocking=True)
-            else:
-                data, byte_off = eb.pack_strings(strs[s0:s0 + n], dev)
+            else:  # a staging buffer per piece, no sync here: the call's final status read orders everything
+                data, byte_off = eb.pack_strings(strs[s0:s0 + n], dev, slot=len(keep))
             if image is not None:
                 ops.rans_decode_image(data, byte_off, rows, nsym, image[0], image[1], sym, 1, B, n, status=status, sym_offset=s0,
                                       rows_shared=True)
@@ -363,7 +363,7 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     return {"strings": [PackedStrings(ys, ysegs), PackedStrings(zs, zsegs)], "shape": torch.Size(shape)}
 
 
-def _upload(strs, pieces, dev):
+def _upload(strs, pieces, dev, id_base=0):
     """Per piece (s0, n): (device bytes, device int64 offsets [n+1]) of strs[s0:s0+n] - straight from compress()'s
     page-locked segments when `strs` still is what compress() returned, else re-joined through a staging buffer."""
     from .entropy_models import EntropyBottleneck
@@ -375,7 +375,7 @@ def _upload(strs, pieces, dev):
             data = host_t[lo4: max(hi, lo4 + 4)].to(dev, non_blocking=True)
             out.append((data, torch.from_numpy(off - lo4).to(dev, non_blocking=True)))
         return out
-    return [EntropyBottleneck.pack_strings(strs[s0:s0 + n], dev) for (s0, n) in pieces]
+    return [EntropyBottleneck.pack_strings(strs[s0:s0 + n], dev, slot=(id_base + k)) for k, (s0, n) in enumerate(pieces)]
 
 
 def decompress_hyper(net, strings, shape, chunk=512):
@@ -421,7 +421,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
     _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
                                                            status=status, off_offset=0))
     z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
-    yup = _upload(ystrs, pieces, dev)
+    yup = _upload(ystrs, pieces, dev, id_base=64)
     fp16 = net.precision == "fp16"
     st = engine.stages(net.g_s)
     cout = st[-1][0].out_channels

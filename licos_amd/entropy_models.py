@@ -357,21 +357,31 @@ class EntropyBottleneck(nn.Module):
         return buf
 
     @classmethod
-    def pack_strings(cls, strings, device):
+    def pack_strings(cls, strings, device, slot=None):
+        """(device bytes, device int64 offsets [n+1]) of a list of strings, through a page-locked staging buffer.
+        `slot` = None: the shared buffer, synchronised before returning (it is reused by the next call).  `slot` = k: a
+        buffer of its own per k and NO synchronisation - for pipelines that pack several pieces back to back and
+        synchronise once at their end (codec.decompress_*: a sync per piece would hold the next piece's upload behind
+        the previous piece's decode launch)."""
         lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=len(strings))
         if np.any(lens % 4) or np.any(lens < 8):
             raise ValueError("licos_amd: every rANS string must be a whole number (>= 2) of 32-bit words")
         byte_off = np.zeros(len(strings) + 1, dtype=np.int64)
         np.cumsum(lens, out=byte_off[1:])
         total = int(byte_off[-1])
-        stage = cls._pinned_buffer(total + 8 * byte_off.size)
+        need = total + 8 * byte_off.size + 8
+        key = "buf" if slot is None else ("slot", int(slot))
+        stage = cls._pinned.get(key)
+        if stage is None or stage.numel() < need:
+            stage = cls._pinned[key] = torch.empty(max(need, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
         view = stage.numpy()
         view[:total] = np.frombuffer(b"".join(strings), dtype=np.uint8)
         pad = (-total) % 8
         off_view = view[total + pad: total + pad + 8 * byte_off.size].view(np.int64)
         off_view[:] = byte_off
         dev_buf = stage[: total + pad + 8 * byte_off.size].to(device, non_blocking=True)
-        torch.cuda.current_stream().synchronize()  # the staging buffer is reused by the next call
+        if slot is None:
+            torch.cuda.current_stream().synchronize()  # the staging buffer is reused by the next call
         return dev_buf[:total], dev_buf[total + pad:].view(torch.int64)
 
     def decode_symbols(self, data, byte_off, batch, n, plane):

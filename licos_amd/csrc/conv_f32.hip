@@ -4,6 +4,7 @@
 // oracle, symbols and therefore rANS bytes identical); it is a VALU kernel family with
 // LDS-staged input patches and weights.  The throughput path is conv_mfma.hip.
 #include "common.hpp"
+#include "mfma_common.hpp"
 
 namespace licos {
 
@@ -280,6 +281,10 @@ int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff,
                   int inverse, void *stream) {
   LICOS_REQUIRE(x && gamma_eff && beta_eff && y, "gdn_f32: NULL buffer");
   LICOS_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0, "gdn_f32: bad shape");
+  // 128 channels, whole 32-pixel tiles, 16-byte aligned rows: the one-pass matrix-core kernel (mfma_gdn_f32.hip)
+  static const bool use_mfma = [] { const char *e = getenv("LICOS_GDN_F32_MFMA"); return !(e && e[0] == '0'); }();
+  if (use_mfma && C == 128 && HW % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
+    return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, B, HW, inverse, as_stream(stream));
   const size_t lds = (size_t)C * 64 * sizeof(float);
   LICOS_REQUIRE(lds <= 64 * 1024, "gdn_f32: C=%d needs %zu B of LDS (max 65536)", C, lds);
   hipLaunchKernelGGL(gdn_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, gamma_eff, beta_eff,

@@ -283,7 +283,19 @@ int mfma_try_conv3x3_tiles(const MfmaArgs &a, int MT, int epi, hipStream_t s);  
 bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv);
 // 9 .. 16 output channels over a whole number of channel PAIRS of chunks: the 16 x 16 x 32 kernel and its weight layout
 // ([pair][tap][lane][8]); everything else: the 32-row kernel and its compact layout.  One rule for packer and launcher.
+// Pins `v` to ONE fp32 register value.  A split operand needs it: with contraction on (HIP's default), `(_Float16)(a * a)`
+// may compile to a fused multiply-convert (v_fma_mixlo_f16: the EXACT product rounded to fp16 once) at one use and to
+// v_cvt_pk_f16_f32 of the fp32-rounded product at another.  In the rare double-rounding cases (~5 per 100 000 values)
+// the two high parts differ by one fp16 ulp, the residual is then taken against the wrong one, and the element is off
+// by 2^-11 relative (found by the fp32 GDN parity test).  __fmul_rn alone does not stop it.
+__device__ __forceinline__ float pin_f32(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
 inline bool fewch_uses_16x16x32(int Cin, int Cout) { return Cout > 8 && Cout <= 16 && Cin % 32 == 0; }
-int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
+int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);
+// fp32 GDN / IGDN over 128 channels on the matrix cores (mfma_gdn_f32.hip); HW must be a multiple of 32 and rows 16-byte aligned
+int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, long HW, int inverse,
+                        hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
 
 }  // namespace licos

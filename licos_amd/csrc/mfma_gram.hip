@@ -40,7 +40,8 @@ __device__ inline void gram_stage(const float *__restrict__ t, const float *__re
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float val = which ? (v[e] * 0.0625f) * (v[e] * 0.0625f) : v[e] * t_scale;
+      // (pin_f32: one fp32 value for both the high part and its residual - mfma_common.hpp)
+      const float val = pin_f32(which ? (v[e] * 0.0625f) * (v[e] * 0.0625f) : v[e] * t_scale);
       hi[e] = (_Float16)val;
       lo[e] = (_Float16)((val - (float)hi[e]) * 2048.f);
     }

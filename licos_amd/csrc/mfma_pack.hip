@@ -209,6 +209,7 @@ __global__ void nchw_to_blk16_kernel(const float *__restrict__ x, _Float16 *__re
         v0 *= 0.0625f; v1 *= 0.0625f;
         v0 *= v0; v1 *= v1;
       }
+      v0 = pin_f32(v0); v1 = pin_f32(v1);  // one fp32 value for the high part and its residual (mfma_common.hpp)
       lo[j] = (_Float16)v0;
       hi[j] = (_Float16)v1;
       rlo[j] = (_Float16)((v0 - (float)lo[j]) * res_scale);  // scaled up so the residual keeps all 11 bits (no fp16 subnormals)

@@ -243,8 +243,8 @@ def gdn_f32(x, gamma_eff, beta_eff, inverse=False):
     _dev(x, gamma_eff, beta_eff)
     b, c = x.shape[:2]
     hw = x[0, 0].numel()
-    # (the forward stays on the direct kernel: one product, and the VALU kernel does it as fast as three MFMA passes
-    # plus operand splitting; the backward, two products per element, is where the matrix cores pay - gdn_bwd_f32)
+    # (128 channels over whole 32-pixel tiles run as ONE pass on the matrix cores, mfma_gdn_f32.hip; other shapes on the
+    # vector-ALU kernel)
     y = torch.empty_like(x)
     rc = _lib.load().licos_gdn_f32(_p(_f32(x)), _p(gamma_eff), _p(beta_eff), _p(y), b, c, hw, int(inverse), _stream())
     _lib.check(rc, "gdn_f32")

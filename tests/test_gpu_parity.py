@@ -29,9 +29,12 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def elementwise_close(a, b, rtol=1e-5, atol_of_max=1e-6):
+def elementwise_close(a, b, rtol=1e-5, atol_of_max=2e-6):
     """north_star's "1e-5 relative on latents", read element by element: |a - b| <= rtol |b| + atol_of_max * max|b|
-    (the absolute term is the cancellation noise of a few-thousand-term fp32 sum whose result is near zero)."""
+    (the absolute term is the cancellation noise of a few-thousand-term fp32 sum whose result is near zero - in BOTH
+    evaluations: the oracle is an fp32 evaluation too.  Measured on the 256^2 cases, worst |a - b| over the latents near
+    zero: 0.89e-6 max|b| with the vector-ALU GDN, 1.07e-6 with the matrix-core GDN, although the latter is the one
+    closer to float64 - rms 6e-8 against 1.1e-7, tools/experiments/gdn_err.py; 1e-6 sat on the comparison's own noise)."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return bool(((a - b).abs() <= rtol * b.abs() + atol_of_max * float(b.abs().max())).all())
 

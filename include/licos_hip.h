@@ -338,6 +338,17 @@ int licos_blk16_to_nchw_f32(const void *x_blk16, float *y, int B, int C, int H, 
 int licos_nchw_f32_split_blk16(const float *x, void *y_hi_blk16, void *y_lo_blk16, int B, int C, int H, int W, int abs_input,
                                int lo_shift, void *stream);
 
+/* The split operand of the ONE-launch fp32 convolution: NCHW fp32 -> blk16 fp16 with 3 C channels (zero-padded to a
+ * multiple of 16), channel part * C + c =  hi * 2^-5  |  (x - hi) * 2^6  |  hi = fp16(x)   for part 0 | 1 | 2.
+ * Met along cin by the weights  [ (w - w_hi) * 2^5 | w_hi * 2^-6 | w_hi ]  (split on the caller's side, packed by
+ * licos_pack_conv_w_f16 / licos_pack_conv3x3_w_f16 with Cin = 3 C), the convolution's K loop sums
+ * hi.(w - w_hi) + (x - hi).w_hi + hi.w_hi in ONE fp32 accumulator (the small cross terms first: the running sum is
+ * rounded at every step, and early roundings of a small sum cost nothing): an fp32 convolution to ~1e-6 (the lo.lo
+ * term, 2^-22, is dropped) in one launch and one store - the form of torch's conv2d / conv_transpose2d on the fp32
+ * parity path (licos/train.py:190, eval_utils.py:200).  The power-of-two factors keep every part inside fp16's normal range for
+ * |x| in 2e-3 .. 6e4 and |w| above 4e-3; below, a part loses at most 3e-8 absolute.  abs_input: bit 0 |x|. */
+int licos_nchw_f32_split3_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, int abs_input, void *stream);
+
 /* First analysis stage for few input channels (Cin <= 4: RGB, single Sentinel-2 band): a 5x5 stride-2 conv over
  * Cin channels equals a 3x3 stride-1 conv over the 4*Cin channels of the 2x2 space-to-depth image (channel
  * c*4 + (y&1)*2 + (x&1) at half resolution).  That turns K = 25 taps x 16 padded channels into 9 x 16 and the

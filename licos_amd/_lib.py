@@ -92,6 +92,7 @@ SIGNATURES = {
     "licos_wgrad5x5s2_strips": (_i, [_i, _i, _i]),
     "licos_wgrad5x5s2_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_nchw_f32_split_blk16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_nchw_f32_split3_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_pack_conv3x3_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_conv3x3s1_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_blk16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

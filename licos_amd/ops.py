@@ -91,14 +91,18 @@ def query(device=0):
 
 # ----------------------------------------------------------------------------- 32-bit path
 # ---------------------------------------------------------------------------------------------------------------
-# fp32 through three fp16 MFMA passes.  A 5x5 stride-2 (transposed) convolution in fp32 is the throughput kernels run
-# on split operands: x = x_hi + 2^-11 x_lo, w = w_hi + 2^-11 w_lo (each part fp16, the pair carries ~22 bits), and
-#     y = x_hi*w_hi (+ bias)  +  x_hi*w_lo  +  x_lo*w_hi        (fp32 accumulation; x_lo*w_lo ~ 2^-22 is dropped)
-# Against float64 this is as accurate as torch's fp32 convolution on the CPU (max error 1e-7..1e-6 of max|y|, the
-# direct fp32 VALU kernels: up to 2e-6) and an order of magnitude faster than those kernels.  It serves the fp32
-# parity path and the training step (forward and dgrad); LICOS_FP32_MFMA=0 keeps the VALU kernels.
+# fp32 on the fp16 matrix cores.  A 5x5 stride-2 (transposed) convolution in fp32 is the throughput kernels run on
+# split operands: x = x_hi + x_lo, w = w_hi + w_lo (hi = the fp16 rounding, lo = the residual, ~11 more bits), and
+#     y = bias + x_hi*w_hi + x_hi*w_lo + x_lo*w_hi        (fp32 accumulation; x_lo*w_lo ~ 2^-22 is dropped)
+# as ONE convolution over 3 Cin channels: activations [x_hi 2^-5 | x_lo 2^6 | x_hi] (licos_nchw_f32_split3_blk16), weights
+# [w_lo 2^5 | w_hi 2^-6 | w_hi] along cin - one K loop, one accumulator, one store of the NCHW fp32 result (the earlier
+# form, three launches accumulating into the output, re-read and re-wrote it twice: the first analysis stage spent
+# 25 ms per 1024 tiles on 43 GB of output traffic).  Against float64 this is as accurate as torch's fp32 convolution
+# on the CPU (max error 1e-7..1e-6 of max|y|; the direct fp32 VALU kernels: up to 2e-6) and an order of magnitude faster
+# than those kernels.  It serves the fp32 parity path and the training step (forward and dgrad); LICOS_FP32_MFMA=0
+# keeps the VALU kernels.
 FP32_MFMA = os.environ.get("LICOS_FP32_MFMA", "1") != "0"
-X3_SHIFT = 11  # residual parts are stored as fp16((v - hi) * 2^11): full 11 bits instead of fp16 subnormals
+X3_SHIFT = 11  # (1x1 products, wgrad) residual parts are stored as fp16((v - hi) * 2^11): full 11 bits instead of fp16 subnormals
 _x3_zero_bias = {}
 
 
@@ -112,14 +116,15 @@ def _x3_ok(cin, cout, relu, kind):
 
 
 def _x3_weights(w, kind):
-    """(packed hi, packed lo).  Not cached: a cache keyed on the weight's address and version would serve stale
-    fragments once a freed tensor's address is reused; the split + two packs are six tiny kernels."""
+    """Packed fragments of [(w - w_hi) 2^5 | w_hi 2^-6 | w_hi] along cin.  Not cached: a cache keyed on the weight's
+    address and version would serve stale fragments once a freed tensor's address is reused; split + pack are a few
+    tiny kernels."""
     wf = w.detach().float()
     hi = wf.half().float()
-    lo = (wf - hi) * float(2 ** X3_SHIFT)
+    cat = torch.cat(((wf - hi) * 32.0, hi * 0.015625, hi), dim=0 if kind == "deconv" else 1)
     if kind == "conv3":
-        return pack_conv3x3_w_f16(hi), pack_conv3x3_w_f16(lo)
-    return pack_conv_w_f16(hi, kind == "deconv"), pack_conv_w_f16(lo, kind == "deconv")
+        return pack_conv3x3_w_f16(cat)
+    return pack_conv_w_f16(cat, kind == "deconv")
 
 
 def nchw_f32_split_blk16(x, abs_input=False, square16=False):
@@ -133,25 +138,23 @@ def nchw_f32_split_blk16(x, abs_input=False, square16=False):
     return hi, lo
 
 
+def nchw_f32_split3_blk16(x, abs_input=False):
+    """blk16 fp16 tensor of 3 C channels [hi 2^-5 | (x - hi) 2^6 | hi] (licos_hip.h)."""
+    _dev(x)
+    b, c, h, w = x.shape
+    y = torch.empty((b, (3 * c + 15) // 16, h, w, 16), device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_nchw_f32_split3_blk16(_p(_f32(x)), _p(y), b, c, h, w, int(bool(abs_input)), _stream()),
+               "nchw_f32_split3_blk16")
+    return y
+
+
 def _conv_x3(x, w, bias, relu, abs_input, kind):
     """kind: "conv" (5x5 s2), "deconv" (5x5 s2 transposed, output padding 1), "conv3" (3x3 s1)."""
-    transposed = kind == "deconv"
     cin = x.shape[1]
-    cout = w.shape[1] if transposed else w.shape[0]
-    xh, xl = nchw_f32_split_blk16(x.contiguous(), abs_input)
-    wh, wl = _x3_weights(w, kind)
-    bp = pad_bias(bias, cout, x.device)
-    zk = (32 * mfma_tiles(cout), str(x.device))
-    zero = _x3_zero_bias.get(zk)
-    if zero is None:
-        zero = _x3_zero_bias[zk] = torch.zeros(zk[0], device=x.device, dtype=torch.float32)
+    cout = w.shape[1] if kind == "deconv" else w.shape[0]
     fn = {"conv": conv5x5s2_f16, "deconv": deconv5x5s2_f16, "conv3": conv3x3s1_f16}[kind]
-    down = EPI_ACCUMULATE | (X3_SHIFT << 12)  # LICOS_EPI_SCALE_DOWN: the residual parts were scaled up by 2^X3_SHIFT
-    last = (EPI_RELU if relu else EPI_NONE) | down
-    y = fn(xh, wh, bp, None, EPI_NONE, cin, cout, out_nchw=True)
-    fn(xh, wl, zero, None, EPI_NONE | down, cin, cout, out_nchw=True, out=y)
-    fn(xl, wh, zero, None, last, cin, cout, out_nchw=True, out=y)
-    return y
+    return fn(nchw_f32_split3_blk16(x.contiguous(), abs_input), _x3_weights(w, kind), pad_bias(bias, cout, x.device), None,
+              EPI_RELU if relu else EPI_NONE, 3 * cin, cout, out_nchw=True)
 
 
 def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):

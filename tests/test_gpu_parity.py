@@ -534,9 +534,29 @@ def test_corrupted_strings_never_fault(precision):
         assert torch.equal(net.decompress([base], comp["shape"])["x_hat"], good)
 
 
+@pytest.mark.parametrize("c,h,w,abs_in", [(3, 9, 21, False), (128, 8, 16, True), (13, 5, 7, False), (1, 16, 16, False), (192, 4, 4, False)])
+def test_split3_operand_layout(c, h, w, abs_in):
+    """licos_nchw_f32_split3_blk16: channel part * C + c of the blk16 tensor = fp16(x) 2^-5 | (x - fp16(x)) 2^6 | fp16(x),
+    zero padding to whole 16-channel chunks; hi + lo reproduces x to 2^-22."""
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, h, w, generator=g) * 10.0 ** (2 - 4 * torch.rand(2, c, h, w, generator=g))
+    y = ops.nchw_f32_split3_blk16(x.to(DEV), abs_in).cpu()
+    c16 = (3 * c + 15) // 16
+    assert y.shape == (2, c16, h, w, 16) and y.dtype == torch.float16
+    flat = y.permute(0, 1, 4, 2, 3).reshape(2, c16 * 16, h, w).float()
+    v = x.abs() if abs_in else x
+    hi = v.half().float()
+    assert torch.equal(flat[:, :c], (hi * 2.0 ** -5).half().float())
+    assert torch.equal(flat[:, c:2 * c], ((v - hi) * 64.0).half().float())
+    assert torch.equal(flat[:, 2 * c:3 * c], hi)
+    assert not bool(flat[:, 3 * c:].any())
+    back = flat[:, 2 * c:3 * c].double() + flat[:, c:2 * c].double() / 64.0
+    assert float(((back - v.double()).abs() / v.abs().double().clamp_min(1e-3)).max()) < 2.0 ** -21
+
+
 @pytest.mark.parametrize("cin,cout,relu,abs_in", [(192, 128, True, True), (128, 192, True, False), (128, 320, True, False), (20, 40, False, False)])
 def test_fp32_conv3x3_through_mfma_passes(cin, cout, relu, abs_in):
-    """The hyperprior's 3x3 stride-1 layers (h_a[0] on |y|, h_s[4] + ReLU) take the same three-pass route."""
+    """The hyperprior's 3x3 stride-1 layers (h_a[0] on |y|, h_s[4] + ReLU) take the same split-operand route."""
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(2, cin, 12, 20, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
@@ -559,15 +579,22 @@ def test_fp32_conv3x3_through_mfma_passes(cin, cout, relu, abs_in):
 @pytest.mark.parametrize("cin,cout,h,w,transposed,relu,scale", [
     (128, 128, 64, 64, False, False, 1.0), (3, 128, 64, 64, False, False, 0.5), (128, 192, 32, 32, False, False, 5.0),
     (128, 128, 32, 32, False, True, 0.01), (192, 128, 16, 16, True, False, 3.0), (128, 128, 32, 32, True, True, 1.0),
-    (128, 3, 32, 32, True, False, 1.0), (320, 192, 8, 8, True, False, 1.0), (13, 128, 37, 53, False, False, 1.0)])
+    (128, 3, 32, 32, True, False, 1.0), (320, 192, 8, 8, True, False, 1.0), (13, 128, 37, 53, False, False, 1.0),
+    (128, 128, 32, 32, False, False, 1e-3), (128, 128, 32, 32, True, False, 300.0), (1, 128, 64, 64, False, False, -1.0)])
 def test_fp32_through_three_fp16_mfma_passes(cin, cout, h, w, transposed, relu, scale):
     """conv2d_f32 / deconv2d_f32 route 5x5 stride-2 layers through the MFMA kernels on split operands
-    (x = hi + 2^-11 lo, w likewise; hi*hi + hi*lo + lo*hi, fp32 accumulation).  Judged against float64: at least as
-    accurate as the direct fp32 VALU kernels and within a small factor of torch's own fp32 convolution."""
+    (x = hi + lo, w likewise; hi*hi + hi*lo + lo*hi in one K loop over 3 Cin channels, fp32 accumulation).  Judged
+    against float64: at least as accurate as the direct fp32 VALU kernels and within a small factor of torch's own fp32
+    convolution - also for activations of 1e-3 and of hundreds, and (scale -1) for activations and weights spread over
+    three decades each, where some split parts sit in fp16's subnormal range."""
     g = torch.Generator().manual_seed(cin * 7 + cout)
-    x = torch.randn(2, cin, h, w, generator=g) * scale
     wshape = (cin, cout, 5, 5) if transposed else (cout, cin, 5, 5)
     wt = torch.randn(*wshape, generator=g) * 0.03
+    if scale < 0:
+        x = torch.randn(2, cin, h, w, generator=g) * 10.0 ** (-3 * torch.rand(2, cin, h, w, generator=g))
+        wt = wt * 10.0 ** (-3 * torch.rand(*wshape, generator=g))
+    else:
+        x = torch.randn(2, cin, h, w, generator=g) * scale
     b = torch.randn(cout, generator=g)
     if transposed:
         ref64 = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=2, output_padding=1)

@@ -84,6 +84,13 @@ int licos_gdn_reparam_f32(const float *beta_raw, const float *gamma_raw, float b
  * (sqrt when inverse != 0).  x, y: [B][C][HW] fp32; gamma_eff [C][C]. */
 int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C,
                   int HW, int inverse, void *stream);
+/* The same layer with its result written as the split operand of the NEXT layer's one-launch fp32 convolution
+ * (blk16 fp16, 3 C channels: licos_nchw_f32_split3_blk16's layout) instead of NCHW fp32 - the inference chain of the
+ * fp32 parity path ((I)GDN followed by a 5x5 stride-2 (transposed) convolution).  Served by the one-pass matrix-core
+ * kernel only: licos_gdn_f32_split3_applies(C, HW) != 0 (128 channels, HW a multiple of 32). */
+int licos_gdn_f32_split3_applies(int C, int HW);
+int licos_gdn_f32_split3(const float *x, const float *gamma_eff, const float *beta_eff, void *y_blk16, int B, int C,
+                         int HW, int inverse, void *stream);
 
 /* ------------------------------------------------ backward, 32-bit path
  * What licos/train.py:193 (`loss.backward()`) computes through torch autograd for the transforms.

@@ -277,14 +277,24 @@ int licos_gdn_reparam_f32(const float *beta_raw, const float *gamma_raw, float b
   return LICOS_OK;
 }
 
+int licos_gdn_f32_split3_applies(int C, int HW) { return C == 128 && HW > 0 && HW % 32 == 0 && HW < (1 << 20); }
+
+int licos_gdn_f32_split3(const float *x, const float *gamma_eff, const float *beta_eff, void *y_blk16, int B, int C, int HW,
+                         int inverse, void *stream) {
+  LICOS_REQUIRE(x && gamma_eff && beta_eff && y_blk16 && B > 0, "gdn_f32_split3: bad arguments");
+  LICOS_REQUIRE(licos_gdn_f32_split3_applies(C, HW), "gdn_f32_split3: C=%d HW=%d is not served by the one-pass kernel (ask licos_gdn_f32_split3_applies)", C, HW);
+  LICOS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y_blk16 & 15) == 0, "gdn_f32_split3: buffers must be 16-byte aligned");
+  return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, nullptr, y_blk16, B, HW, inverse, as_stream(stream));
+}
+
 int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C, int HW,
                   int inverse, void *stream) {
   LICOS_REQUIRE(x && gamma_eff && beta_eff && y, "gdn_f32: NULL buffer");
   LICOS_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0, "gdn_f32: bad shape");
   // 128 channels, whole 32-pixel tiles, 16-byte aligned rows: the one-pass matrix-core kernel (mfma_gdn_f32.hip)
   static const bool use_mfma = [] { const char *e = getenv("LICOS_GDN_F32_MFMA"); return !(e && e[0] == '0'); }();
-  if (use_mfma && C == 128 && HW % 32 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
-    return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, B, HW, inverse, as_stream(stream));
+  if (use_mfma && licos_gdn_f32_split3_applies(C, HW) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
+    return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, nullptr, B, HW, inverse, as_stream(stream));
   const size_t lds = (size_t)C * 64 * sizeof(float);
   LICOS_REQUIRE(lds <= 64 * 1024, "gdn_f32: C=%d needs %zu B of LDS (max 65536)", C, lds);
   hipLaunchKernelGGL(gdn_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, gamma_eff, beta_eff,

@@ -294,8 +294,9 @@ __device__ __forceinline__ float pin_f32(float v) {
 }
 inline bool fewch_uses_16x16x32(int Cin, int Cout) { return Cout > 8 && Cout <= 16 && Cin % 32 == 0; }
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);
-// fp32 GDN / IGDN over 128 channels on the matrix cores (mfma_gdn_f32.hip); HW must be a multiple of 32 and rows 16-byte aligned
-int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, long HW, int inverse,
-                        hipStream_t s);  // Cout <= 32, NCHW fp32 out, all 4 phases per workgroup
+// fp32 GDN / IGDN over 128 channels on the matrix cores (mfma_gdn_f32.hip); HW must be a multiple of 32 and rows 16-byte
+// aligned.  Output: NCHW fp32 `y`, or (y_split3 != null) the 3 C-channel split operand of licos_nchw_f32_split3_blk16.
+int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, int B, long HW,
+                        int inverse, hipStream_t s);
 
 }  // namespace licos

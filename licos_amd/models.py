@@ -45,6 +45,20 @@ class TransformSequential(nn.Sequential):
         return run_chain_fp32(self, x)
 
 
+def _takes_split3(gdn, x, nxt, nxt_relu):
+    """A GDN whose consumer is a convolution on the one-launch split-operand route, with no gradient wanted."""
+    if not isinstance(nxt, (nn.Conv2d, nn.ConvTranspose2d)) or x.dim() != 4:
+        return False
+    if autograd.needs_grad(x, gdn.beta, gdn.gamma, nxt.weight, nxt.bias):
+        return False
+    if not ops.gdn_f32_split3_applies(x.shape[1], x.shape[2] * x.shape[3]):
+        return False
+    geo = conv_geometry(nxt)
+    if isinstance(nxt, nn.ConvTranspose2d):
+        return ops.x3_route(nxt.in_channels, nxt.out_channels, geo[0], geo[1], geo[2], geo[3], nxt_relu)
+    return ops.x3_route(nxt.in_channels, nxt.out_channels, geo[0], geo[1], geo[2], None, nxt_relu)
+
+
 def run_chain_fp32(seq, x):
     if x.dtype != torch.float32:
         raise ValueError("licos_amd: inputs must be float32")
@@ -59,19 +73,26 @@ def run_chain_fp32(seq, x):
         first = False
         if isinstance(m, nn.ConvTranspose2d):
             k, s, p, op = conv_geometry(m)
-            if autograd.needs_grad(x, m.weight, m.bias):
+            if not isinstance(x, ops.Split3) and autograd.needs_grad(x, m.weight, m.bias):
                 x = autograd.DeconvHip.apply(x, m.weight, m.bias, s, p, op, relu)  # HIP forward and backward
             else:
                 x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
         elif isinstance(m, nn.Conv2d):
             k, s, p = conv_geometry(m)
-            if autograd.needs_grad(x, m.weight, m.bias):
+            if not isinstance(x, ops.Split3) and autograd.needs_grad(x, m.weight, m.bias):
                 x = autograd.ConvHip.apply(x, m.weight, m.bias, s, p, relu, abs_in)  # HIP forward and backward
             else:
                 x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
                                    abs_input=abs_in)
         elif isinstance(m, GDN):
-            x = m(x)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if _takes_split3(m, x, nxt, i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)):
+                # inference: the result leaves the GDN kernel as the next convolution's split operand (no NCHW fp32
+                # round trip, no separate split pass)
+                beta, gamma = m.effective()
+                x = ops.gdn_f32_split3(x.contiguous(), gamma, beta, m.inverse)
+            else:
+                x = m(x)
             relu = False
         else:
             raise TypeError(f"licos_amd: unsupported module in transform: {type(m).__name__}")

@@ -148,16 +148,48 @@ def nchw_f32_split3_blk16(x, abs_input=False):
     return y
 
 
+class Split3:
+    """An activation tensor already in the split-operand form (blk16 fp16, 3 C channels) - what gdn_f32_split3 hands
+    the next layer's convolution in place of NCHW fp32."""
+
+    def __init__(self, blk, channels):
+        self.blk, self.channels = blk, channels
+
+    @property
+    def shape(self):
+        b, _, h, w, _ = self.blk.shape
+        return (b, self.channels, h, w)
+
+
 def _conv_x3(x, w, bias, relu, abs_input, kind):
     """kind: "conv" (5x5 s2), "deconv" (5x5 s2 transposed, output padding 1), "conv3" (3x3 s1)."""
     cin = x.shape[1]
     cout = w.shape[1] if kind == "deconv" else w.shape[0]
     fn = {"conv": conv5x5s2_f16, "deconv": deconv5x5s2_f16, "conv3": conv3x3s1_f16}[kind]
-    return fn(nchw_f32_split3_blk16(x.contiguous(), abs_input), _x3_weights(w, kind), pad_bias(bias, cout, x.device), None,
-              EPI_RELU if relu else EPI_NONE, 3 * cin, cout, out_nchw=True)
+    if isinstance(x, Split3):
+        if abs_input:
+            raise ValueError("licos_amd: |x| is taken when the operand is split, not afterwards")
+        blk = x.blk
+    else:
+        blk = nchw_f32_split3_blk16(x.contiguous(), abs_input)
+    return fn(blk, _x3_weights(w, kind), pad_bias(bias, cout, blk.device), None, EPI_RELU if relu else EPI_NONE, 3 * cin, cout,
+              out_nchw=True)
+
+
+def x3_route(cin, cout, k, stride, pad, out_pad=None, relu=False):
+    """Whether conv2d_f32 (out_pad None) / deconv2d_f32 sends this layer through the one-launch split-operand form."""
+    if not FP32_MFMA:
+        return False
+    if out_pad is None:
+        return ((k, stride, pad) == (5, 2, 2) and _x3_ok(cin, cout, relu, "conv")) or ((k, stride, pad) == (3, 1, 1) and _x3_ok(cin, cout, relu, "conv3"))
+    return (k, stride, pad, out_pad) == (5, 2, 2, 1) and _x3_ok(cin, cout, relu, "deconv")
 
 
 def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
+    if isinstance(x, Split3):
+        if not x3_route(x.channels, w.shape[0], w.shape[2], stride, pad, None, relu):
+            raise ValueError("licos_amd: a split operand was prepared for a layer that does not take it")
+        return _conv_x3(x, w, bias, relu, abs_input, "conv" if w.shape[2] == 5 else "conv3")
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cout, cin_w, k, k2 = w.shape
@@ -176,6 +208,10 @@ def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
 
 
 def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False):
+    if isinstance(x, Split3):
+        if not x3_route(x.channels, w.shape[1], w.shape[2], stride, pad, out_pad, relu):
+            raise ValueError("licos_amd: a split operand was prepared for a layer that does not take it")
+        return _conv_x3(x, w, bias, relu, False, "deconv")
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cin_w, cout, k, k2 = w.shape
@@ -240,6 +276,20 @@ def _gdn_pointwise(x, n, dy, u, inverse, mode):
 
 def _gdn_mfma_ok(x):
     return GDN_MFMA and FP32_MFMA and x.dim() == 4 and x.shape[1] in (128, 192)
+
+
+def gdn_f32_split3_applies(c, hw):
+    return FP32_MFMA and bool(_lib.load().licos_gdn_f32_split3_applies(c, hw))
+
+
+def gdn_f32_split3(x, gamma_eff, beta_eff, inverse=False):
+    """GDN / IGDN whose result is the next convolution's split operand (Split3) instead of NCHW fp32."""
+    _dev(x, gamma_eff, beta_eff)
+    b, c, h, w = x.shape
+    y = torch.empty((b, 3 * c // 16, h, w, 16), device=x.device, dtype=torch.float16)
+    rc = _lib.load().licos_gdn_f32_split3(_p(_f32(x)), _p(gamma_eff), _p(beta_eff), _p(y), b, c, h * w, int(inverse), _stream())
+    _lib.check(rc, "gdn_f32_split3")
+    return Split3(y, c)
 
 
 def gdn_f32(x, gamma_eff, beta_eff, inverse=False):

@@ -101,6 +101,27 @@ def test_gdn_f32(c, hw, inverse):
     assert rel_err(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_f32_split3_output(inverse):
+    """licos_gdn_f32_split3 = licos_gdn_f32 followed by licos_nchw_f32_split3_blk16, bit for bit (the inference chain
+    of the fp32 path hands the next convolution its split operand straight from the GDN kernel)."""
+    c = 128
+    m = licos_amd.GDN(c, inverse=inverse).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        m.gamma.add_(0.05 * torch.rand(c, c, generator=g).to(DEV))
+    beta, gamma = m.effective()
+    x = (3 * torch.randn(3, c, 8, 20, generator=g)).to(DEV)
+    assert ops.gdn_f32_split3_applies(c, 8 * 20)
+    assert not ops.gdn_f32_split3_applies(c, 8 * 21) and not ops.gdn_f32_split3_applies(192, 8 * 20)
+    y = ops.gdn_f32(x, gamma, beta, inverse)
+    s3 = ops.gdn_f32_split3(x, gamma, beta, inverse)
+    assert s3.shape == tuple(x.shape)
+    assert torch.equal(s3.blk, ops.nchw_f32_split3_blk16(y))
+    ref = om.gdn(x.cpu(), {"g." + k: v.cpu() for k, v in m.state_dict().items()}, "g.", inverse=inverse)
+    assert rel_err(y, ref) < 1e-5
+
+
 @pytest.mark.parametrize("cin", [3, 1, 13])
 def test_entropy_bottleneck_forward(cin):
     sd = om.perturb_state(om.make_factorized_state(cin, 1), seed=cin)

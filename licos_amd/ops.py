@@ -172,6 +172,12 @@ def _conv_x3(x, w, bias, relu, abs_input, kind):
         blk = x.blk
     else:
         blk = nchw_f32_split3_blk16(x.contiguous(), abs_input)
+    if kind == "deconv" and cout <= 32 and not relu:
+        # the last synthesis stage: all four output phases of a tile from one staged patch (mfma_deconv.hip, few-channel form)
+        wf = w.detach().float()
+        hi = wf.half().float()
+        wp = pack_deconv_w_fewch_f16(torch.cat(((wf - hi) * 32.0, hi * 0.015625, hi), dim=0))
+        return deconv5x5s2_fewch_f16(blk, wp, pad_bias(bias, cout, blk.device), 3 * cin, cout)
     return fn(blk, _x3_weights(w, kind), pad_bias(bias, cout, blk.device), None, EPI_RELU if relu else EPI_NONE, 3 * cin, cout,
               out_nchw=True)
 

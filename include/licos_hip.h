@@ -329,6 +329,10 @@ size_t licos_packed_conv_w_bytes(int Cin, int Cout);
 int licos_pack_conv_w_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_pack_deconv_w_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 size_t licos_packed_gdn_bytes(int C);
+/* for LICOS_EPI_NORM32 (0 bytes: C not served) */
+size_t licos_packed_gdn_f32split_bytes(int C);
+int licos_pack_gdn_f32split(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
+                            float pedestal, int C, void *packed, void *stream);
 int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
                         float pedestal, int C, void *packed, void *stream);
 /* NCHW fp32 -> blk16 fp16 (channels zero-padded to a multiple of 16); abs_input != 0 stores |x| (ScaleHyperprior h_a) */
@@ -434,6 +438,15 @@ int licos_allreduce_weighted_direct(float *bucket, long n, long n_alloc, float c
 /* with LICOS_EPI_ACCUMULATE: y_nchw += 2^-k * result, k = 0..63 - undoes the 2^k by which a residual operand was scaled
  * up before its conversion to fp16 (licos_nchw_f32_split_blk16's lo_shift, the weight residual likewise) */
 #define LICOS_EPI_SCALE_DOWN(k) (((k) & 63) << 12)
+/* OR-ed into `epilogue` with LICOS_EPI_GDN / LICOS_EPI_IGDN (65..128 output channels): the norm at fp32 accuracy -
+ * `gdn_packed` is then licos_pack_gdn_f32split's buffer (256 gamma split hi + 2^-11 lo in fp16; squares of the
+ * accumulators split the same way in registers; hi.hi + 2^-11 (hi.lo + lo.hi) on the matrix cores, rsqrt / sqrt to
+ * 1 ulp).  On a split-operand input (licos_nchw_f32_split3_blk16) this is the fp32 parity path's conv + GDN as ONE kernel:
+ * the same values as licos_gdn_f32 applied to the convolution's fp32 result. */
+#define LICOS_EPI_NORM32 0x40000
+/* OR-ed into `epilogue` (blk16 output, Cout a multiple of 16): `y_blk16` receives 3 Cout channels, the split operand of
+ * the NEXT fp32 convolution (licos_nchw_f32_split3_blk16's layout) - built from the fp32 result in registers. */
+#define LICOS_EPI_OUT_SPLIT3 0x80000
 /* OR-ed into licos_deconv5x5s2_f16's `epilogue`: the blk16 input / output is in the x-split form
  *   [B][C/16][H][2][W/2][16]   (each row as two half rows: its even-x pixels, then its odd-x pixels; W even).
  * One output phase of a transposed convolution writes every other pixel of a row; x-split, that is one contiguous run

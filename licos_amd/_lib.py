@@ -76,6 +76,8 @@ SIGNATURES = {
     "licos_pack_deconv_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_packed_gdn_bytes": (_c.c_size_t, [_i]),
     "licos_pack_gdn_bf16": (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp]),
+    "licos_packed_gdn_f32split_bytes": (_c.c_size_t, [_i]),
+    "licos_pack_gdn_f32split": (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp]),
     "licos_nchw_f32_to_s2d_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_pack_conv_w_s2d_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_conv5x5s2_s2d_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

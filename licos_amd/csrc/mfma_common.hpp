@@ -28,7 +28,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int EPI_NONE = LICOS_EPI_NONE, EPI_GDN = LICOS_EPI_GDN, EPI_IGDN = LICOS_EPI_IGDN, EPI_RELU = LICOS_EPI_RELU;
+// internal: (I)GDN with LICOS_EPI_NORM32 - the norm at fp32 accuracy (fp16-split gamma fragments, licos_pack_gdn_f32split)
+constexpr int EPI_GDN32 = 4, EPI_IGDN32 = 5;
+__host__ __device__ constexpr bool epi_norm(int epi) { return epi == EPI_GDN || epi == EPI_IGDN || epi == EPI_GDN32 || epi == EPI_IGDN32; }
+__host__ __device__ constexpr bool epi_norm32(int epi) { return epi == EPI_GDN32 || epi == EPI_IGDN32; }
+// 16-byte granules of the packed gamma fragments an epilogue keeps in LDS
+__host__ __device__ constexpr int epi_gamma_gran(int epi, int MT) { return epi_norm(epi) ? MT * MT * 2 * 64 * (epi_norm32(epi) ? 2 : 1) : 0; }
 
+// Pins `v` to ONE fp32 register value.  A split operand needs it: with contraction on (HIP's default), `(_Float16)(a * a)`
+// may compile to a fused multiply-convert (v_fma_mixlo_f16: the EXACT product rounded to fp16 once) at one use and to
+// v_cvt_pk_f16_f32 of the fp32-rounded product at another.  In the rare double-rounding cases (~5 per 100 000 values)
+// the two high parts differ by one fp16 ulp, the residual is then taken against the wrong one, and the element is off
+// by 2^-11 relative (found by the fp32 GDN parity test).  __fmul_rn alone does not stop it.
+__device__ __forceinline__ float pin_f32(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
 __host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---- geometry shared by host and device ---------------------------------------------------------
@@ -138,9 +153,116 @@ struct MfmaArgs {
   const void *zero16;     // 16 bytes of zeros in global memory (source of out-of-image granules)
   int in_xsplit, out_xsplit;  // LICOS_EPI_IN_XSPLIT / LICOS_EPI_OUT_XSPLIT (mfma_deconv8.hip only)
   int w_mt_total, halves;     // mfma_conv8.hip pair mode: 32-channel tiles in the packed weights, channel groups per tile
+  int out_split3;             // LICOS_EPI_OUT_SPLIT3: y_blk holds 3 Cout channels, the split operand of the next fp32 convolution
 };
 
 // ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
+// One accumulator tile (32 channels x 32 pixels) leaves as: blk16 fp16 | the 3 Cout-channel split operand of the next fp32
+// convolution | NCHW fp32 (optionally accumulated into).  `scale`: the (I)GDN factor per register, or null.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store_tile(const f32x16 &acc, const f32x16 *scale, const MfmaArgs &a, int b, int oy, int ox,
+                                                    int lane, int it, int c_base) {
+  const int h = lane >> 5;
+  const int Cout16 = (a.Cout + 15) >> 4;
+  const bool live = oy < a.Ho && ox < a.Wo && oy >= 0;
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  if (a.y_blk && a.out_split3) {
+    // chunks [hi 2^-5 | (v - hi) 2^6 | hi] of 3 Cout channels (licos_nchw_f32_split3_blk16); lane / permlane pattern as the
+    // blk16 store below
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      unsigned lo3[3][2], hi3[3][2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        half2v ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float v = acc[8 * gp + 4 * side + 2 * d + e];
+            if (epi_norm(EPI)) v *= (*scale)[8 * gp + 4 * side + 2 * d + e];
+            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+            v = pin_f32(v);
+            const _Float16 hv = (_Float16)v;
+            ph[side][e] = hv;
+            pl[side][e] = (_Float16)((v - (float)hv) * 64.f);
+          }
+        const half2v k5 = {(_Float16)0.03125f, (_Float16)0.03125f};
+        pm[0] = ph[0] * k5;
+        pm[1] = ph[1] * k5;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          const half2v *src = part == 0 ? pm : part == 1 ? pl : ph;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, src[0]), __builtin_bit_cast(unsigned, src[1]), false, false);
+          lo3[part][d] = sw[0];
+          hi3[part][d] = sw[1];
+        }
+      }
+      const int chunk = (c_base >> 4) + 2 * it + gp;
+      if (live && chunk < Cout16) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          _Float16 *dst = a.y_blk + ((((size_t)b * 3 * Cout16 + part * Cout16 + chunk) * a.Ho + oy) * a.Wo + ox) * 16 + 8 * h;
+          *reinterpret_cast<uint4 *>(dst) = make_uint4(lo3[part][0], lo3[part][1], hi3[part][0], hi3[part][1]);
+        }
+      }
+    }
+  } else if (a.y_blk) {
+    // blk16: a 16-channel chunk of a pixel is 32 B.  A lane holds channels {0-3, 8-11} (+4 for the
+    // upper half-wave) of the chunk; one v_permlane32_swap per dword hands the lower lane channels
+    // 0-7 and the upper lane 8-15, so each lane stores ONE 16-byte piece (half as many stores).
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      unsigned lo[2], hi[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        float v0[2], v1[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          v0[e] = acc[8 * gp + 2 * d + e];
+          v1[e] = acc[8 * gp + 4 + 2 * d + e];
+          if (epi_norm(EPI)) {
+            v0[e] *= (*scale)[8 * gp + 2 * d + e];
+            v1[e] *= (*scale)[8 * gp + 4 + 2 * d + e];
+          }
+          if (EPI == EPI_RELU) {
+            v0[e] = fmaxf(v0[e], 0.f);
+            v1[e] = fmaxf(v1[e], 0.f);
+          }
+        }
+        half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
+        lo[d] = __builtin_bit_cast(unsigned, p0);
+        hi[d] = __builtin_bit_cast(unsigned, p1);
+        const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+        lo[d] = sw[0];
+        hi[d] = sw[1];
+      }
+      const int chunk = (c_base >> 4) + 2 * it + gp;
+      if (live && chunk < Cout16) {
+        _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + chunk) * a.Ho + oy) * a.Wo + ox) * 16 + 8 * h;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = c_base + 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[4 * g + e];
+        if (epi_norm(EPI)) v *= (*scale)[4 * g + e];
+        if (live && c0 + e < a.Cout) {
+          float *dst = a.y_nchw + (((size_t)b * a.Cout + c0 + e) * a.Ho + oy) * a.Wo + ox;
+          if (a.accum) v = fmaf(v, a.out_scale, *dst);
+          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+          if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 template <int MT, int NT, int EPI>
 __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, const bf16x8 *gamma, int b,
                                       const int (&oy)[NT], const int (&ox)[NT], int lane, int c_base = 0) {
@@ -162,107 +284,107 @@ __device__ inline void epilogue_store(f32x16 (&acc)[MT][NT], const MfmaArgs &a, 
       }
     }
   }
-  const int Cout16 = (a.Cout + 15) >> 4;
+  // (static_for, not `#pragma unroll`: with the fp32-norm body the compiler kept this loop rolled and indexed the
+  // accumulators through scratch)
+  static_for<MT>([&](auto itc) {
+    constexpr int it = decltype(itc)::value;
+    if constexpr (EPI == EPI_GDN32 || EPI == EPI_IGDN32) {
+      // the norm at fp32 accuracy: (acc / 16)^2 split hi + 2^-11 lo in registers (the accumulator tile is the B operand as
+      // it stands), 256 gamma split the same way as A fragments [it][jt][s][hi | lo][lane]; hi.hi in `norm`, the two
+      // cross terms in `normx` (mfma_gdn_f32.hip is the stand-alone form of this).  One pixel tile at a time - norm,
+      // factor, store - : both at once do not fit the register file next to the accumulators.
+      const half8 *g32 = reinterpret_cast<const half8 *>(gamma);
 #pragma unroll
-  for (int it = 0; it < MT; ++it) {
-    f32x16 scale[NT];
-    if (EPI == EPI_GDN || EPI == EPI_IGDN) {
-      // norm tile `it` = beta + sum_jt sum_s gamma(it, jt, s) x sq(acc[jt], regs 8s..8s+7)
-      f32x16 norm[NT];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4 *>(a.beta + 32 * it + 8 * g + 4 * h);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          norm[nt][4 * g + 0] = bv.x;
-          norm[nt][4 * g + 1] = bv.y;
-          norm[nt][4 * g + 2] = bv.z;
-          norm[nt][4 * g + 3] = bv.w;
-        }
-      }
-#pragma unroll
-      for (int jt = 0; jt < MT; ++jt) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 gfrag = gamma[((it * MT + jt) * 2 + s) * 64 + lane];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            bf16x8 sq;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float v = acc[jt][nt][8 * s + e];
-              sq[e] = (__bf16)(v * v);
-            }
-            norm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfrag, sq, norm[nt], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          scale[nt][q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[nt][q]) : __builtin_amdgcn_sqrtf(norm[nt][q]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool live = oy[nt] < a.Ho && ox[nt] < a.Wo && oy[nt] >= 0;
-      if (a.y_blk) {
-        // blk16: a 16-channel chunk of a pixel is 32 B.  A lane holds channels {0-3, 8-11} (+4 for the
-        // upper half-wave) of the chunk; one v_permlane32_swap per dword hands the lower lane channels
-        // 0-7 and the upper lane 8-15, so each lane stores ONE 16-byte piece (half as many stores).
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          unsigned lo[2], hi[2];
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            float v0[2], v1[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              v0[e] = acc[it][nt][8 * gp + 2 * d + e];
-              v1[e] = acc[it][nt][8 * gp + 4 + 2 * d + e];
-              if (EPI == EPI_GDN || EPI == EPI_IGDN) {
-                v0[e] *= scale[nt][8 * gp + 2 * d + e];
-                v1[e] *= scale[nt][8 * gp + 4 + 2 * d + e];
-              }
-              if (EPI == EPI_RELU) {
-                v0[e] = fmaxf(v0[e], 0.f);
-                v1[e] = fmaxf(v1[e], 0.f);
-              }
-            }
-            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-            half2v p0 = {(_Float16)v0[0], (_Float16)v0[1]}, p1 = {(_Float16)v1[0], (_Float16)v1[1]};
-            lo[d] = __builtin_bit_cast(unsigned, p0);
-            hi[d] = __builtin_bit_cast(unsigned, p1);
-            const auto sw = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
-            lo[d] = sw[0];
-            hi[d] = sw[1];
-          }
-          const int chunk = (c_base >> 4) + 2 * it + gp;
-          if (live && chunk < Cout16) {
-            _Float16 *dst = a.y_blk + ((((size_t)b * Cout16 + chunk) * a.Ho + oy[nt]) * a.Wo + ox[nt]) * 16 + 8 * h;
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
-          }
-        }
-      } else {
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 norm, normx;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int c0 = c_base + 32 * it + 8 * g + 4 * h;  // 4 consecutive channels c0..c0+3
+          const float4 bv = *reinterpret_cast<const float4 *>(a.beta + 32 * it + 8 * g + 4 * h);
+          norm[4 * g + 0] = bv.x;
+          norm[4 * g + 1] = bv.y;
+          norm[4 * g + 2] = bv.z;
+          norm[4 * g + 3] = bv.w;
+          normx[4 * g + 0] = normx[4 * g + 1] = normx[4 * g + 2] = normx[4 * g + 3] = 0.f;
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[it][nt][4 * g + e];
-            if (EPI == EPI_GDN || EPI == EPI_IGDN) v *= scale[nt][4 * g + e];
-            if (live && c0 + e < a.Cout) {
-              float *dst = a.y_nchw + (((size_t)b * a.Cout + c0 + e) * a.Ho + oy[nt]) * a.Wo + ox[nt];
-              if (a.accum) v = fmaf(v, a.out_scale, *dst);
-              if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-              if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-              *dst = v;
+        for (int jt = 0; jt < MT; ++jt) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8 gh = g32[(((it * MT + jt) * 2 + s) * 2 + 0) * 64 + lane], gl = g32[(((it * MT + jt) * 2 + s) * 2 + 1) * 64 + lane];
+            half8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              // (volatile: keeps the compiler from sharing the 128 registers of scaled / squared / split accumulators
+              // between the four output tiles - recomputing them is cheaper than the spills)
+              float t = acc[jt][nt][8 * s + e];
+              asm volatile("" : "+v"(t));
+              const float v = t * 0.0625f;
+              const float sq = pin_f32(v * v);
+              bh[e] = (_Float16)sq;
+              bl[e] = (_Float16)((sq - (float)bh[e]) * 2048.f);
+            }
+            norm = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bh, norm, 0, 0, 0);
+            normx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bl, normx, 0, 0, 0);
+            normx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, bh, normx, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          // norm >= beta_min > 0: v_rsq_f32 (1 ulp) + one Newton step; sqrt = norm * rsqrt
+          const float n = norm[q] + normx[q] * (1.f / 2048.f);
+          const float r0 = __builtin_amdgcn_rsqf(n);
+          if (EPI == EPI_IGDN32) {
+            const float s0 = n * r0;
+            norm[q] = fmaf(fmaf(-s0, s0, n), 0.5f * r0, s0);
+          } else {
+            norm[q] = fmaf(0.5f * r0, fmaf(-n * r0, r0, 1.f), r0);
+          }
+        }
+        epilogue_store_tile<EPI>(acc[it][nt], &norm, a, b, oy[nt], ox[nt], lane, it, c_base);
+      }
+    } else {
+      f32x16 scale[NT];
+      if (EPI == EPI_GDN || EPI == EPI_IGDN) {
+        // norm tile `it` = beta + sum_jt sum_s gamma(it, jt, s) x sq(acc[jt], regs 8s..8s+7)
+        f32x16 norm[NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4 *>(a.beta + 32 * it + 8 * g + 4 * h);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            norm[nt][4 * g + 0] = bv.x;
+            norm[nt][4 * g + 1] = bv.y;
+            norm[nt][4 * g + 2] = bv.z;
+            norm[nt][4 * g + 3] = bv.w;
+          }
+        }
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const bf16x8 gfrag = gamma[((it * MT + jt) * 2 + s) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              bf16x8 sq;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float v = acc[jt][nt][8 * s + e];
+                sq[e] = (__bf16)(v * v);
+              }
+              norm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfrag, sq, norm[nt], 0, 0, 0);
             }
           }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            scale[nt][q] = (EPI == EPI_GDN) ? __builtin_amdgcn_rsqf(norm[nt][q]) : __builtin_amdgcn_sqrtf(norm[nt][q]);
       }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epilogue_store_tile<EPI>(acc[it][nt], &scale[nt], a, b, oy[nt], ox[nt], lane, it, c_base);
     }
-  }
+  });
 }
 
 
@@ -283,15 +405,6 @@ int mfma_try_conv3x3_tiles(const MfmaArgs &a, int MT, int epi, hipStream_t s);  
 bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool accum, bool s1conv);
 // 9 .. 16 output channels over a whole number of channel PAIRS of chunks: the 16 x 16 x 32 kernel and its weight layout
 // ([pair][tap][lane][8]); everything else: the 32-row kernel and its compact layout.  One rule for packer and launcher.
-// Pins `v` to ONE fp32 register value.  A split operand needs it: with contraction on (HIP's default), `(_Float16)(a * a)`
-// may compile to a fused multiply-convert (v_fma_mixlo_f16: the EXACT product rounded to fp16 once) at one use and to
-// v_cvt_pk_f16_f32 of the fp32-rounded product at another.  In the rare double-rounding cases (~5 per 100 000 values)
-// the two high parts differ by one fp16 ulp, the residual is then taken against the wrong one, and the element is off
-// by 2^-11 relative (found by the fp32 GDN parity test).  __fmul_rn alone does not stop it.
-__device__ __forceinline__ float pin_f32(float v) {
-  asm("" : "+v"(v));
-  return v;
-}
 inline bool fewch_uses_16x16x32(int Cin, int Cout) { return Cout > 8 && Cout <= 16 && Cin % 32 == 0; }
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);
 // fp32 GDN / IGDN over 128 channels on the matrix cores (mfma_gdn_f32.hip); HW must be a multiple of 32 and rows 16-byte

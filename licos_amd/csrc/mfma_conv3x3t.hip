@@ -142,7 +142,7 @@ static int launch_conv3x3t(const MfmaArgs &a0, hipStream_t s) {
 
 // returns LICOS_OK after launching, or 1 when this variant does not apply (caller falls back to the general kernels)
 int mfma_try_conv3x3_tiles(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
-  if (!a.s1conv || a.Cin16 != 1 || MT != 4 || a.H < 16 || a.W < 32 || !a.y_blk || a.accum) return 1;
+  if (!a.s1conv || a.Cin16 != 1 || MT != 4 || a.H < 16 || a.W < 32 || !a.y_blk || a.accum || a.out_split3) return 1;
   if (epi == EPI_GDN) return launch_conv3x3t<4, EPI_GDN>(a, s);
   if (epi == EPI_NONE) return launch_conv3x3t<4, EPI_NONE>(a, s);
   if (epi == EPI_RELU) return launch_conv3x3t<4, EPI_RELU>(a, s);

@@ -229,9 +229,9 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_mfma8_kernel(MfmaArgs a) {
     return;
   }
   const bf16x8 *gam = a.gamma;
-  if (EPI == EPI_GDN || EPI == EPI_IGDN) {
+  if (epi_norm(EPI)) {
     bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
-    for (int g = tid; g < G::GAMMA_GRAN; g += 512) s_gamma[g] = a.gamma[g];
+    for (int g = tid; g < epi_gamma_gran(EPI, MT); g += 512) s_gamma[g] = a.gamma[g];
     __syncthreads();
     gam = s_gamma;
   }
@@ -244,8 +244,8 @@ static int launch_conv8(const MfmaArgs &a0, hipStream_t s) {
   MfmaArgs a = a0;
   a.tiles_x = cdiv(a.Wo, G::TW);
   a.tiles_y = cdiv(a.Ho, G::TH);
-  const size_t lds = TILE_EPI ? (size_t)(G::TOTAL_GRAN + G::GAMMA_GRAN) * 16 + 2 * 32 * MT * sizeof(float)
-                              : (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::TOTAL_GRAN * 16;
+  const size_t kloop = (size_t)G::TOTAL_GRAN * 16, gam = (size_t)epi_gamma_gran(EPI, MT) * 16;
+  const size_t lds = TILE_EPI ? (size_t)(G::TOTAL_GRAN + G::GAMMA_GRAN) * 16 + 2 * 32 * MT * sizeof(float) : (kloop > gam ? kloop : gam);
   auto kern = conv5x5s2_mfma8_kernel<MT, EPI, false, TILE_EPI>;
   LICOS_ENSURE_LDS(kern, lds);
   LICOS_REQUIRE((long)a.tiles_x * a.tiles_y * a.B < (1L << 31), "conv5x5s2_f16: grid too large");
@@ -285,7 +285,8 @@ int mfma_try_conv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
     if (MT == 4 && epi == EPI_RELU) return launch_conv8_pair<4, EPI_RELU>(a, 4, s);
   }
   if (MT != 4 || a.Ho < 16 || a.Wo < 32 || (a.Ho % 16) != 0) return 1;
-  if (epi == EPI_GDN) return (a.y_blk && !a.accum) ? launch_conv8<4, EPI_GDN, true>(a, s) : launch_conv8<4, EPI_GDN>(a, s);
+  if (epi == EPI_GDN) return (a.y_blk && !a.accum && !a.out_split3) ? launch_conv8<4, EPI_GDN, true>(a, s) : launch_conv8<4, EPI_GDN>(a, s);
+  if (epi == EPI_GDN32) return launch_conv8<4, EPI_GDN32>(a, s);
   if (epi == EPI_NONE) return launch_conv8<4, EPI_NONE>(a, s);
   if (epi == EPI_RELU) return launch_conv8<4, EPI_RELU>(a, s);
   return 1;

@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256, (MT <= 6 ? 2 : 1)) void deconv5x5s2_mfma_kerne
     }
   }
   const bf16x8 *gam = a.gamma;
-  if (EPI == EPI_GDN || EPI == EPI_IGDN) {
+  if (epi_norm(EPI)) {
     bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(smem);
-    for (int g = tid; g < G::GAMMA_GRAN; g += 256) s_gamma[g] = a.gamma[g];
+    for (int g = tid; g < epi_gamma_gran(EPI, MT); g += 256) s_gamma[g] = a.gamma[g];
     __syncthreads();
     gam = s_gamma;
   }
@@ -153,7 +153,8 @@ static int launch_deconv(const MfmaArgs &a0, hipStream_t s) {
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
   // gamma fragments share the K-loop buffers' space; only (I)GDN epilogues need room for them
-  const size_t lds = (EPI == EPI_GDN || EPI == EPI_IGDN) ? (size_t)G::LDS_BYTES : (size_t)G::KLOOP_GRAN * 16;
+  const size_t kloop = (size_t)G::KLOOP_GRAN * 16, gam = (size_t)epi_gamma_gran(EPI, MT) * 16;
+  const size_t lds = kloop > gam ? kloop : gam;
   auto kern = deconv5x5s2_mfma_kernel<MT, NT, TH, TW, EPI>;
   LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)a.tiles_x * a.tiles_y * (a.s1conv ? 1 : 4) * a.B;
@@ -183,6 +184,8 @@ int mfma_dispatch_deconv(const MfmaArgs &a, int MT, int epi, int width, hipStrea
   if (MT == 4 && epi == EPI_NONE) return dispatch_tile<4, EPI_NONE>(a, width, s);
   if (MT == 4 && epi == EPI_GDN) return dispatch_tile<4, EPI_GDN>(a, width, s);
   if (MT == 4 && epi == EPI_IGDN) return dispatch_tile<4, EPI_IGDN>(a, width, s);
+  if (MT == 4 && epi == EPI_GDN32) return dispatch_tile<4, EPI_GDN32>(a, width, s);
+  if (MT == 4 && epi == EPI_IGDN32) return dispatch_tile<4, EPI_IGDN32>(a, width, s);
   if (MT == 6 && epi == EPI_NONE) return dispatch_tile<6, EPI_NONE>(a, width, s);
   if (MT == 6 && epi == EPI_GDN) return dispatch_tile<6, EPI_GDN>(a, width, s);
   if (MT == 6 && epi == EPI_IGDN) return dispatch_tile<6, EPI_IGDN>(a, width, s);

@@ -230,7 +230,7 @@ bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool ac
 }
 
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
-  if (!mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, a.y_blk != nullptr, a.accum != 0, a.s1conv != 0)) return 1;
+  if (!mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, a.y_blk != nullptr && !a.out_split3, a.accum != 0, a.s1conv != 0)) return 1;
   if (a.W == 16) {
     LICOS_REQUIRE((long)a.Cin16 * a.H * a.W * 2 < (1L << 30), "deconv5x5s2_f16: image too large");
     if (epi == EPI_IGDN) return launch_deconv8<4, EPI_IGDN, true>(a, s);

@@ -123,6 +123,39 @@ __global__ void pack_gdn_kernel(const float *__restrict__ beta_raw, const float 
   }
 }
 
+// The same reparametrised gamma for LICOS_EPI_NORM32: 256 gamma split hi + 2^-11 lo in fp16, fragments
+// [it][jt][s][hi | lo][lane][8] (k-permuted as above), then beta [32 MT] fp32
+__global__ void pack_gdn_f32split_kernel(const float *__restrict__ beta_raw, const float *__restrict__ gamma_raw,
+                                         float beta_bound, float gamma_bound, float pedestal, int C, int MT,
+                                         _Float16 *__restrict__ gout, float *__restrict__ bout) {
+  const long total = (long)MT * MT * 2 * 64 * 8;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int s = (int)(rest & 1); rest >>= 1;
+    const int jt = (int)(rest % MT), it = (int)(rest / MT);
+    const int i = 32 * it + (lane & 31), j = 32 * jt + 16 * s + 8 * (el >> 2) + 4 * (lane >> 5) + (el & 3);
+    float v = 0.f;
+    if (i < C && j < C) {
+      const float g = fmaxf(gamma_raw[(size_t)i * C + j], gamma_bound);
+      v = (g * g - pedestal) * 256.f;
+    }
+    v = pin_f32(v);
+    const _Float16 hi = (_Float16)v;
+    const size_t frag = (size_t)((it * MT + jt) * 2 + s) * 2;
+    gout[((frag + 0) * 64 + lane) * 8 + el] = hi;
+    gout[((frag + 1) * 64 + lane) * 8 + el] = (_Float16)((v - (float)hi) * 2048.f);
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * MT; i += gridDim.x * blockDim.x) {
+    float v = 1.f;  // padded channels: norm = 1 keeps rsqrt/sqrt finite
+    if (i < C) {
+      const float t = fmaxf(beta_raw[i], beta_bound);
+      v = t * t - pedestal;
+    }
+    bout[i] = v;
+  }
+}
+
 // space-to-depth conv weights: [Cout][Cin][5][5] -> phase-0-style fragments [cc][t = iky*3+ikx][mt][lane][8] of the
 // equivalent 3x3 stride-1 conv over channels c*4 + py*2 + px (see licos_conv5x5s2_s2d_f16)
 __global__ void pack_conv_w_s2d_kernel(const float *__restrict__ w, int Cin, int Cout, int C16, int MT,
@@ -357,6 +390,23 @@ int licos_pack_gdn_bf16(const float *beta_raw, const float *gamma_raw, float bet
   return LICOS_OK;
 }
 
+size_t licos_packed_gdn_f32split_bytes(int C) {
+  if (C <= 0 || C > 128) return 0;  // LICOS_EPI_NORM32 is instantiated for the 128-channel (four-tile) kernels
+  return (size_t)4 * 4 * 2 * 2 * 1024 + (size_t)32 * 4 * sizeof(float);
+}
+
+int licos_pack_gdn_f32split(const float *beta_raw, const float *gamma_raw, float beta_bound, float gamma_bound,
+                            float pedestal, int C, void *packed, void *stream) {
+  LICOS_REQUIRE(beta_raw && gamma_raw && packed && licos_packed_gdn_f32split_bytes(C) > 0 && mt_for(C) == 4, "pack_gdn_f32split: unsupported C=%d (65..128)", C);
+  const int MT = 4;
+  _Float16 *g = static_cast<_Float16 *>(packed);
+  float *bta = reinterpret_cast<float *>(static_cast<unsigned char *>(packed) + (size_t)MT * MT * 2 * 2 * 1024);
+  hipLaunchKernelGGL(pack_gdn_f32split_kernel, dim3(64), dim3(256), 0, as_stream(stream), beta_raw, gamma_raw, beta_bound,
+                     gamma_bound, pedestal, C, MT, g, bta);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
 int licos_nchw_f32_to_s2d_blk16(const float *x, void *y_blk16, int B, int C, int H, int W, void *stream) {
   LICOS_REQUIRE(x && y_blk16 && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "nchw_f32_to_s2d_blk16: bad arguments (H, W must be even)");
   LICOS_REQUIRE(((uintptr_t)x & 7) == 0, "nchw_f32_to_s2d_blk16: input must be 8-byte aligned");
@@ -450,6 +500,13 @@ static const void *zero_page() {
   return p;
 }
 
+// the kernels' epilogue code of a public `epilogue` word: (I)GDN with LICOS_EPI_NORM32 -> EPI_GDN32 / EPI_IGDN32
+static int kernel_epi(int epilogue) {
+  const int epi = epilogue & 0xff;
+  if ((epilogue & LICOS_EPI_NORM32) && (epi == EPI_GDN || epi == EPI_IGDN)) return epi == EPI_GDN ? EPI_GDN32 : EPI_IGDN32;
+  return epi;
+}
+
 static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bias, const void *gdn, int epi,
                      void *y_blk, float *y_nchw, int B, int Cin, int H, int W, int Cout, int *MT_out, const char *who) {
   LICOS_REQUIRE(x && wp && bias, "%s: NULL buffer", who);
@@ -460,7 +517,10 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   LICOS_REQUIRE((epi != EPI_GDN && epi != EPI_IGDN) || gdn, "%s: (I)GDN epilogue needs packed gamma/beta", who);
   const int accum = (epi & LICOS_EPI_ACCUMULATE) ? 1 : 0;
   const int down = (epi >> 12) & 63;  // LICOS_EPI_SCALE_DOWN(k)
+  const int norm32 = (epi & LICOS_EPI_NORM32) ? 1 : 0, split3 = (epi & LICOS_EPI_OUT_SPLIT3) ? 1 : 0;
   epi &= 0xff;
+  LICOS_REQUIRE(!norm32 || ((epi == EPI_GDN || epi == EPI_IGDN) && MT == 4), "%s: LICOS_EPI_NORM32 goes with an (I)GDN epilogue over 65..128 channels", who);
+  LICOS_REQUIRE(!split3 || (y_blk && Cout % 16 == 0 && !accum), "%s: LICOS_EPI_OUT_SPLIT3 needs a blk16 output buffer (3 Cout channels) and Cout a multiple of 16", who);
   LICOS_REQUIRE(down == 0 || accum, "%s: LICOS_EPI_SCALE_DOWN goes with LICOS_EPI_ACCUMULATE", who);
   LICOS_REQUIRE(epi >= 0 && epi <= 3, "%s: bad epilogue %d", who, epi);
   LICOS_REQUIRE(!accum || (y_nchw && epi != EPI_GDN && epi != EPI_IGDN), "%s: LICOS_EPI_ACCUMULATE needs an NCHW fp32 output and no (I)GDN", who);
@@ -469,7 +529,8 @@ static int fill_args(MfmaArgs &a, const void *x, const void *wp, const float *bi
   a.wp = static_cast<const half8 *>(wp);
   a.bias = bias;
   a.gamma = static_cast<const bf16x8 *>(gdn);
-  a.beta = gdn ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(gdn) + (size_t)MT * MT * 2 * 1024) : nullptr;
+  a.beta = gdn ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(gdn) + (size_t)MT * MT * 2 * 1024 * (norm32 ? 2 : 1)) : nullptr;
+  a.out_split3 = split3;
   a.y_blk = static_cast<_Float16 *>(y_blk);
   a.y_nchw = y_nchw;
   a.B = B;
@@ -497,7 +558,7 @@ int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *
   if (rc != LICOS_OK) return rc;
   a.Ho = (H - 1) / 2 + 1;
   a.Wo = (W - 1) / 2 + 1;
-  return mfma_dispatch_conv(a, MT, epilogue & 0xff, a.Wo, as_stream(stream));
+  return mfma_dispatch_conv(a, MT, kernel_epi(epilogue), a.Wo, as_stream(stream));
 }
 
 int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
@@ -517,7 +578,7 @@ int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float
                   "deconv5x5s2_f16: the x-split layout is not available for this stage (see licos_deconv5x5s2_f16_layouts)");
     LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_f16: x-split input needs an even width");
   }
-  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, kernel_epi(epilogue), W, as_stream(stream));
 }
 
 int licos_deconv5x5s2_f16_layouts(int Cin, int H, int W, int Cout) {
@@ -539,7 +600,7 @@ extern "C" int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_pa
   a.Ho = H / 2;
   a.Wo = W / 2;
   a.s1conv = 1;  // 3x3 stride-1 taps = output phase (0,0) of the transposed-conv kernel without the upsampling
-  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W / 2, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, kernel_epi(epilogue), W / 2, as_stream(stream));
 }
 
 extern "C" int licos_deconv5x5s2_fewch_f16(const void *x_blk16, const void *w_packed_fewch, const float *bias, float *y_nchw,
@@ -566,5 +627,5 @@ extern "C" int licos_conv3x3s1_f16(const void *x_blk16, const void *w_packed, co
   a.Ho = H;
   a.Wo = W;
   a.s1conv = 1;
-  return mfma_dispatch_deconv(a, MT, epilogue & 0xff, W, as_stream(stream));
+  return mfma_dispatch_deconv(a, MT, kernel_epi(epilogue), W, as_stream(stream));
 }

@@ -60,6 +60,8 @@ class GDN(nn.Module):
         self.gamma = nn.Parameter(gamma)
         self._eff_key = None
         self._eff = None
+        self._p32_key = None
+        self._p32 = None
 
     def reparam_args(self):
         """(beta_bound, gamma_bound, pedestal) as the kernels take them."""
@@ -74,6 +76,16 @@ class GDN(nn.Module):
             self._eff = ops.gdn_reparam_f32(self.beta.detach(), self.gamma.detach(), bb, gb, ped)
             self._eff_key = key
         return self._eff
+
+    def packed_f32split(self):
+        """The operand of a convolution epilogue that applies this layer at fp32 accuracy (ops.EPI_NORM32), cached like
+        effective(); None when the channel count is not served."""
+        key = (self.beta.data_ptr(), self.beta._version, self.gamma.data_ptr(), self.gamma._version, ops.weights_epoch())
+        if self._p32_key != key:
+            bb, gb, ped = self.reparam_args()
+            self._p32 = ops.pack_gdn_f32split(self.beta.detach(), self.gamma.detach(), bb, gb, ped)
+            self._p32_key = key
+        return self._p32
 
     def forward(self, x):
         from . import autograd

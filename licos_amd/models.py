@@ -14,6 +14,8 @@ precision:
           arithmetic and identical rANS bytes (parity path);
   "fp16"  fused MFMA pipeline (throughput path, BASELINE.json configs[1]).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -22,6 +24,9 @@ import math
 
 from .entropy_models import EntropyBottleneck, GaussianConditional
 from .layers import GDN, conv, conv_geometry, deconv
+
+
+FUSE_FP32 = os.environ.get("LICOS_FUSE_FP32", "1") != "0"  # A/B switch: the fp32 chain layer by layer (NCHW fp32 between all of them)
 
 
 class TransformSequential(nn.Sequential):
@@ -45,21 +50,36 @@ class TransformSequential(nn.Sequential):
         return run_chain_fp32(self, x)
 
 
+def _x3_layer(m, relu):
+    """Is this conv module served by the one-launch split-operand form (ops.x3_route)?"""
+    if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        return False
+    geo = conv_geometry(m)
+    if isinstance(m, nn.ConvTranspose2d):
+        return ops.x3_route(m.in_channels, m.out_channels, geo[0], geo[1], geo[2], geo[3], relu)
+    return ops.x3_route(m.in_channels, m.out_channels, geo[0], geo[1], geo[2], None, relu)
+
+
+def _is_relu(mods, i):
+    return i < len(mods) and isinstance(mods[i], nn.ReLU)
+
+
 def _takes_split3(gdn, x, nxt, nxt_relu):
-    """A GDN whose consumer is a convolution on the one-launch split-operand route, with no gradient wanted."""
+    """A stand-alone GDN whose consumer is a convolution on the one-launch split-operand route, with no gradient wanted."""
     if not isinstance(nxt, (nn.Conv2d, nn.ConvTranspose2d)) or x.dim() != 4:
         return False
     if autograd.needs_grad(x, gdn.beta, gdn.gamma, nxt.weight, nxt.bias):
         return False
     if not ops.gdn_f32_split3_applies(x.shape[1], x.shape[2] * x.shape[3]):
         return False
-    geo = conv_geometry(nxt)
-    if isinstance(nxt, nn.ConvTranspose2d):
-        return ops.x3_route(nxt.in_channels, nxt.out_channels, geo[0], geo[1], geo[2], geo[3], nxt_relu)
-    return ops.x3_route(nxt.in_channels, nxt.out_channels, geo[0], geo[1], geo[2], None, nxt_relu)
+    return _x3_layer(nxt, nxt_relu)
 
 
 def run_chain_fp32(seq, x):
+    """The transform on the fp32 kernels.  Without gradients (the parity path of compress / decompress / eval forward) the
+    chain is fused where the kernels allow it: a convolution on the split-operand route applies the (I)GDN that follows
+    it in its epilogue (ops.EPI_NORM32) and hands the next such convolution its operand already split (ops.Split3) - no
+    NCHW fp32 round trip between the two, the values of the unfused chain."""
     if x.dtype != torch.float32:
         raise ValueError("licos_amd: inputs must be float32")
     x = x.contiguous()
@@ -68,35 +88,51 @@ def run_chain_fp32(seq, x):
     first = True
     while i < len(mods):
         m = mods[i]
-        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        relu = _is_relu(mods, i + 1)
         abs_in = first and getattr(seq, "abs_input", False)
         first = False
-        if isinstance(m, nn.ConvTranspose2d):
-            k, s, p, op = conv_geometry(m)
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            transposed = isinstance(m, nn.ConvTranspose2d)
+            geo = conv_geometry(m)
+            bias = None if m.bias is None else m.bias.detach()
             if not isinstance(x, ops.Split3) and autograd.needs_grad(x, m.weight, m.bias):
-                x = autograd.DeconvHip.apply(x, m.weight, m.bias, s, p, op, relu)  # HIP forward and backward
+                if transposed:
+                    x = autograd.DeconvHip.apply(x, m.weight, m.bias, geo[1], geo[2], geo[3], relu)  # HIP forward and backward
+                else:
+                    x = autograd.ConvHip.apply(x, m.weight, m.bias, geo[1], geo[2], relu, abs_in)
+                i += 2 if relu else 1
+                continue
+            # inference: what can ride in this layer's epilogue
+            gdn, step = None, (2 if relu else 1)
+            if FUSE_FP32 and _x3_layer(m, relu) and m.out_channels > 32:
+                g = mods[i + 1] if i + 1 < len(mods) else None
+                # (the norm rides with forward convolutions only: the transposed kernels that write fp32 work one output
+                # phase of an 8 x 32 tile per workgroup, and 64 KB of gamma fragments per such workgroup cost more than
+                # the IGDN kernel they would save - measured 233 against 135 ms per 4096 tiles)
+                if (isinstance(g, GDN) and not relu and not transposed and not autograd.needs_grad(g.beta, g.gamma)
+                        and g.in_channels == m.out_channels and g.packed_f32split() is not None):
+                    gdn, step = (g.packed_f32split(), g.inverse), 2
+                nxt = mods[i + step] if i + step < len(mods) else None
+                split3 = (m.out_channels % 16 == 0 and _x3_layer(nxt, _is_relu(mods, i + step + 1))
+                          and not autograd.needs_grad(nxt.weight, nxt.bias))
             else:
-                x = ops.deconv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, op, relu)
-        elif isinstance(m, nn.Conv2d):
-            k, s, p = conv_geometry(m)
-            if not isinstance(x, ops.Split3) and autograd.needs_grad(x, m.weight, m.bias):
-                x = autograd.ConvHip.apply(x, m.weight, m.bias, s, p, relu, abs_in)  # HIP forward and backward
+                split3 = False
+            if transposed:
+                x = ops.deconv2d_f32(x, m.weight.detach(), bias, geo[1], geo[2], geo[3], relu, gdn=gdn, split3_out=split3)
             else:
-                x = ops.conv2d_f32(x, m.weight.detach(), None if m.bias is None else m.bias.detach(), s, p, relu,
-                                   abs_input=abs_in)
+                x = ops.conv2d_f32(x, m.weight.detach(), bias, geo[1], geo[2], relu, abs_input=abs_in, gdn=gdn, split3_out=split3)
+            i += step
         elif isinstance(m, GDN):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if _takes_split3(m, x, nxt, i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)):
-                # inference: the result leaves the GDN kernel as the next convolution's split operand (no NCHW fp32
-                # round trip, no separate split pass)
+            if FUSE_FP32 and _takes_split3(m, x, nxt, _is_relu(mods, i + 2)):
+                # a GDN no convolution could take along: its own kernel, the result already split for the next layer
                 beta, gamma = m.effective()
                 x = ops.gdn_f32_split3(x.contiguous(), gamma, beta, m.inverse)
             else:
                 x = m(x)
-            relu = False
+            i += 1
         else:
             raise TypeError(f"licos_amd: unsupported module in transform: {type(m).__name__}")
-        i += 2 if relu else 1
     return x
 
 

@@ -161,8 +161,10 @@ class Split3:
         return (b, self.channels, h, w)
 
 
-def _conv_x3(x, w, bias, relu, abs_input, kind):
-    """kind: "conv" (5x5 s2), "deconv" (5x5 s2 transposed, output padding 1), "conv3" (3x3 s1)."""
+def _conv_x3(x, w, bias, relu, abs_input, kind, gdn=None, split3_out=False):
+    """kind: "conv" (5x5 s2), "deconv" (5x5 s2 transposed, output padding 1), "conv3" (3x3 s1).
+    gdn = (packed f32split operand, inverse): the layer's (I)GDN runs in the convolution's epilogue (EPI_NORM32);
+    split3_out: the result is the next convolution's split operand (Split3) instead of NCHW fp32."""
     cin = x.shape[1]
     cout = w.shape[1] if kind == "deconv" else w.shape[0]
     fn = {"conv": conv5x5s2_f16, "deconv": deconv5x5s2_f16, "conv3": conv3x3s1_f16}[kind]
@@ -172,14 +174,20 @@ def _conv_x3(x, w, bias, relu, abs_input, kind):
         blk = x.blk
     else:
         blk = nchw_f32_split3_blk16(x.contiguous(), abs_input)
-    if kind == "deconv" and cout <= 32 and not relu:
+    if kind == "deconv" and cout <= 32 and not relu and gdn is None and not split3_out:
         # the last synthesis stage: all four output phases of a tile from one staged patch (mfma_deconv.hip, few-channel form)
         wf = w.detach().float()
         hi = wf.half().float()
         wp = pack_deconv_w_fewch_f16(torch.cat(((wf - hi) * 32.0, hi * 0.015625, hi), dim=0))
         return deconv5x5s2_fewch_f16(blk, wp, pad_bias(bias, cout, blk.device), 3 * cin, cout)
-    return fn(blk, _x3_weights(w, kind), pad_bias(bias, cout, blk.device), None, EPI_RELU if relu else EPI_NONE, 3 * cin, cout,
-              out_nchw=True)
+    epi = EPI_RELU if relu else EPI_NONE
+    if gdn is not None:
+        epi = (EPI_IGDN if gdn[1] else EPI_GDN) | EPI_NORM32
+    if split3_out:
+        epi |= EPI_OUT_SPLIT3
+    y = fn(blk, _x3_weights(w, kind), pad_bias(bias, cout, blk.device), None if gdn is None else gdn[0], epi, 3 * cin, cout,
+           out_nchw=not split3_out)
+    return Split3(y, cout) if split3_out else y
 
 
 def x3_route(cin, cout, k, stride, pad, out_pad=None, relu=False):
@@ -191,11 +199,12 @@ def x3_route(cin, cout, k, stride, pad, out_pad=None, relu=False):
     return (k, stride, pad, out_pad) == (5, 2, 2, 1) and _x3_ok(cin, cout, relu, "deconv")
 
 
-def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
-    if isinstance(x, Split3):
-        if not x3_route(x.channels, w.shape[0], w.shape[2], stride, pad, None, relu):
-            raise ValueError("licos_amd: a split operand was prepared for a layer that does not take it")
-        return _conv_x3(x, w, bias, relu, abs_input, "conv" if w.shape[2] == 5 else "conv3")
+def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False, gdn=None, split3_out=False):
+    """gdn / split3_out (see _conv_x3): only for layers on the split-operand route (x3_route) with a norm32_ok() GDN."""
+    if isinstance(x, Split3) or gdn is not None or split3_out:
+        if not x3_route(x.shape[1], w.shape[0], w.shape[2], stride, pad, None, relu):
+            raise ValueError("licos_amd: split operands / fused fp32 GDN need a layer on the split-operand route")
+        return _conv_x3(x, w, bias, relu, abs_input, "conv" if w.shape[2] == 5 else "conv3", gdn, split3_out)
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cout, cin_w, k, k2 = w.shape
@@ -213,11 +222,11 @@ def conv2d_f32(x, w, bias, stride, pad, relu=False, abs_input=False):
     return y
 
 
-def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False):
-    if isinstance(x, Split3):
-        if not x3_route(x.channels, w.shape[1], w.shape[2], stride, pad, out_pad, relu):
-            raise ValueError("licos_amd: a split operand was prepared for a layer that does not take it")
-        return _conv_x3(x, w, bias, relu, False, "deconv")
+def deconv2d_f32(x, w, bias, stride, pad, out_pad, relu=False, gdn=None, split3_out=False):
+    if isinstance(x, Split3) or gdn is not None or split3_out:
+        if not x3_route(x.shape[1], w.shape[1], w.shape[2], stride, pad, out_pad, relu):
+            raise ValueError("licos_amd: split operands / fused fp32 GDN need a layer on the split-operand route")
+        return _conv_x3(x, w, bias, relu, False, "deconv", gdn, split3_out)
     _dev(x, w, bias)
     b, cin, h, wd = x.shape
     cin_w, cout, k, k2 = w.shape
@@ -781,6 +790,7 @@ def rans_decode_host(data, byte_off, n, plane, cdf, cdf_len, offset, batch, inde
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_RELU = 0, 1, 2, 3
 EPI_ACCUMULATE = 0x100  # licos_hip.h LICOS_EPI_ACCUMULATE
 EPI_IN_XSPLIT, EPI_OUT_XSPLIT = 0x200, 0x400  # licos_hip.h: blk16 rows stored as [even-x pixels][odd-x pixels]
+EPI_NORM32, EPI_OUT_SPLIT3 = 0x40000, 0x80000  # licos_hip.h: (I)GDN norm at fp32 accuracy; output = the next fp32 convolution's split operand
 
 
 def deconv_layouts(cin, h, w, cout):
@@ -848,6 +858,20 @@ def pack_gdn_bf16(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
     return packed
 
 
+def pack_gdn_f32split(beta_raw, gamma_raw, beta_bound, gamma_bound, pedestal):
+    """Packed operand of EPI_NORM32 (None: this channel count is not served)."""
+    _dev(beta_raw, gamma_raw)
+    c = beta_raw.numel()
+    nbytes = _lib.load().licos_packed_gdn_f32split_bytes(c)
+    if nbytes == 0 or mfma_tiles(c) != 4:
+        return None
+    packed = torch.empty(nbytes, device=beta_raw.device, dtype=torch.uint8)
+    rc = _lib.load().licos_pack_gdn_f32split(_p(_f32(beta_raw)), _p(_f32(gamma_raw)), beta_bound, gamma_bound, pedestal, c,
+                                             _p(packed), _stream())
+    _lib.check(rc, "pack_gdn_f32split")
+    return packed
+
+
 def nchw_f32_to_blk16(x, abs_input=False):
     _dev(x)
     b, c, h, w = x.shape
@@ -883,7 +907,7 @@ def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
         y = _out_nchw(out, (b, cout, ho, wo), x_blk.device)
         yb, yn = None, y
     else:
-        y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)
+        y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), ho, wo, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
     rc = _lib.load().licos_conv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                          _p(yn), b, cin, h, w, cout, _stream())
@@ -902,7 +926,7 @@ def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cou
         y = _out_nchw(out, (b, cout, ho, wo), x_blk.device)
         yb, yn = None, y
     else:
-        y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_blk.device, dtype=torch.float16)
+        y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), ho, wo, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
     rc = _lib.load().licos_deconv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                            _p(yn), int(clamp01), b, cin, h, w, cout, _stream())
@@ -1013,7 +1037,7 @@ def conv3x3s1_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
         y = _out_nchw(out, (b, cout, h, w), x_blk.device)
         yb, yn = None, y
     else:
-        y = torch.empty((b, (cout + 15) // 16, h, w, 16), device=x_blk.device, dtype=torch.float16)
+        y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), h, w, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
     rc = _lib.load().licos_conv3x3s1_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                          _p(yn), b, cin, h, w, cout, _stream())

@@ -122,6 +122,30 @@ def test_gdn_f32_split3_output(inverse):
     assert rel_err(y, ref) < 1e-5
 
 
+@pytest.mark.parametrize("model,cin,size", [("bmshj2018-factorized", 3, 256), ("bmshj2018-factorized", 13, 64),
+                                             ("bmshj2018-hyperprior", 13, 128), ("bmshj2018-factorized", 1, 96)])
+def test_fp32_chain_fusion_changes_nothing(model, cin, size, monkeypatch):
+    """Inference on the fp32 path fuses each (I)GDN into the epilogue of the convolution in front of it and passes split
+    operands from layer to layer (models.run_chain_fp32); layer by layer (LICOS_FUSE_FP32=0) the same transforms give
+    the same values up to the order of the norm's sums."""
+    from licos_amd import models, synthetic
+    net = licos_amd.get_model(model, False, cin, 2).to(DEV).eval().set_precision("fp32")
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=3)
+    x = om.synthetic_tiles(3, cin, size, seed=5, kind="s2-merged" if cin == 13 else "aid" if cin == 3 else "s2").to(DEV)
+    chains = [net.g_a, net.g_s] + ([net.h_a, net.h_s] if hasattr(net, "h_a") else [])
+    with torch.no_grad():
+        y = net.g_a(x)
+        inputs = {net.g_a: x, net.g_s: torch.round(y), **({net.h_a: y, net.h_s: torch.round(net.h_a(y))} if hasattr(net, "h_a") else {})}
+        for chain in chains:
+            monkeypatch.setattr(models, "FUSE_FP32", True)
+            fused = chain(inputs[chain])
+            monkeypatch.setattr(models, "FUSE_FP32", False)
+            plain = chain(inputs[chain])
+            assert fused.shape == plain.shape and fused.dtype == torch.float32
+            assert rel_err(fused, plain) < 2e-6, chain
+
+
 @pytest.mark.parametrize("cin", [3, 1, 13])
 def test_entropy_bottleneck_forward(cin):
     sd = om.perturb_state(om.make_factorized_state(cin, 1), seed=cin)

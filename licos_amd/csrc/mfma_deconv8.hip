@@ -23,7 +23,9 @@
 
 namespace licos {
 
-template <int MT, int EPI, bool PAIR = false>
+// F32: NCHW fp32 output (the fp32 parity path's one-launch split-operand layers; epilogue NONE / RELU): 128 dword stores
+// per wave and phase - more than a counted vmcnt can leave in flight, so every step waits for vmcnt(0).
+template <int MT, int EPI, bool PAIR = false, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   using G = Deconv8Geom<MT>;
   constexpr int NT = G::NT;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   }
 
   int base[NT], oyh[NT], oxh[NT];  // output position of the input pixel at phase (0, 0); row -1 = outside the map
-  bool all_live = a.Cout >= 32 * MT - 15;
+  bool all_live = !F32 && a.Cout >= 32 * MT - 15;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int ty = wave * NT + nt, tx = PAIR ? (r & 15) : r;
@@ -193,8 +195,29 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
       pix[nt] = !live ? -1 : (a.out_xsplit ? ((long)oy * 2 + px) * a.W + oxh[nt] : (long)oy * a.Wo + ox);
       if (PAIR && live) pix[nt] += (long)img * Cout16 * a.Ho * a.Wo;  // the second image's planes
     }
-    tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, a.y_blk + (size_t)(PAIR ? 2 * b : b) * Cout16 * a.Ho * a.Wo * 16,
-                                (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    if constexpr (F32) {
+      static_assert(!F32 || EPI == EPI_NONE || EPI == EPI_RELU, "the fp32 output has no (I)GDN epilogue");
+      const unsigned plane_px = (unsigned)(a.Ho * a.Wo);
+      float *yb = a.y_nchw + (size_t)(PAIR ? 2 * b : b) * a.Cout * plane_px;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (pix[nt] < 0) continue;
+        // (PAIR: pix carries the second image's blk16 plane offset, img * Cout16 planes; here the image is Cout planes)
+        const unsigned p0 = (unsigned)(pix[nt] - (PAIR ? (long)img * Cout16 * plane_px : 0)) + (PAIR ? (unsigned)img * a.Cout * plane_px : 0u);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int c = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
+            float v = acc[mt][nt][q];
+            if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+            if (c < a.Cout) yb[(unsigned)c * plane_px + p0] = v;
+          }
+      }
+    } else {
+      tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, a.y_blk + (size_t)(PAIR ? 2 * b : b) * Cout16 * a.Ho * a.Wo * 16,
+                                  (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    }
     if (phase + 1 < nphase) acc_init();
   };
   run_phase(I3{}, I3{}, std::integral_constant<int, 0>{});
@@ -205,18 +228,18 @@ __global__ __launch_bounds__(512, 2) void deconv5x5s2_mfma8_kernel(MfmaArgs a) {
   }
 }
 
-template <int MT, int EPI, bool PAIR = false>
+template <int MT, int EPI, bool PAIR = false, bool F32 = false>
 static int launch_deconv8(const MfmaArgs &a0, hipStream_t s) {
   using G = Deconv8Geom<MT>;
   MfmaArgs a = a0;
   a.tiles_x = PAIR ? 1 : cdiv(a.W, G::TW);
   a.tiles_y = cdiv(a.H, G::TH);
   const size_t lds = (size_t)16 * (G::KLOOP_GRAN + 16 * MT + ((EPI == EPI_GDN || EPI == EPI_IGDN) ? G::GAMMA_GRAN : 0));
-  auto kern = deconv5x5s2_mfma8_kernel<MT, EPI, PAIR>;
+  auto kern = deconv5x5s2_mfma8_kernel<MT, EPI, PAIR, F32>;
   LICOS_ENSURE_LDS(kern, lds);
   const long blocks = (long)a.tiles_x * a.tiles_y * (PAIR ? (a.B + 1) / 2 : a.B);  // a workgroup walks all four phases of its tile
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_f16: grid too large");
-  LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * 32 * (PAIR ? 2 : 1) < (1L << 32), "deconv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");
+  LICOS_REQUIRE((long)a.Ho * a.Wo * ((a.Cout + 15) / 16) * (F32 ? 64 : 32) * (PAIR ? 2 : 1) < (1L << 32), "deconv5x5s2_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
@@ -230,6 +253,16 @@ bool mfma_deconv8_applies(int MT, int Cin16, int H, int W, bool blk_out, bool ac
 }
 
 int mfma_try_deconv8(const MfmaArgs &a, int MT, int epi, hipStream_t s) {
+  // NCHW fp32 output, no accumulation, no (I)GDN, no clamp: the fp32 parity path's layers
+  static const bool f32_enabled = [] { const char *e = getenv("LICOS_DECONV8_F32"); return !(e && e[0] == '0'); }();
+  if (f32_enabled && a.y_nchw && !a.y_blk && !a.accum && !a.clamp01 && !a.in_xsplit && !a.out_xsplit && (epi == EPI_NONE || epi == EPI_RELU) &&
+      mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, true, false, a.s1conv != 0) && a.Cout > 32) {
+    if (a.W == 16) {
+      LICOS_REQUIRE((long)a.Cin16 * a.H * a.W * 2 < (1L << 30), "deconv5x5s2_f16: image too large");
+      return epi == EPI_NONE ? launch_deconv8<4, EPI_NONE, true, true>(a, s) : launch_deconv8<4, EPI_RELU, true, true>(a, s);
+    }
+    return epi == EPI_NONE ? launch_deconv8<4, EPI_NONE, false, true>(a, s) : launch_deconv8<4, EPI_RELU, false, true>(a, s);
+  }
   if (!mfma_deconv8_applies(MT, a.Cin16, a.H, a.W, a.y_blk != nullptr && !a.out_split3, a.accum != 0, a.s1conv != 0)) return 1;
   if (a.W == 16) {
     LICOS_REQUIRE((long)a.Cin16 * a.H * a.W * 2 < (1L << 30), "deconv5x5s2_f16: image too large");

@@ -113,6 +113,14 @@ int licos_bias_grad_f32(const float *dy /*[B][C][HW]*/, float *db /*[C]*/, int B
  * licos_bias_grad_f32(t)); gamma_t_scratch: C*C floats. */
 int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, const float *beta_eff,
                       float *gamma_t_scratch, float *dx, float *t_out, int B, int C, int HW, int inverse, void *stream);
+/* The same backward pass for the shapes of licos_gdn_f32_split3_applies (128 channels, HW a multiple of 32) as ONE kernel on
+ * the matrix cores: licos_gdn_f32_fwd_norm is licos_gdn_f32 that also writes norm = beta + gamma . x^2 (NCHW fp32),
+ * licos_gdn_bwd_fused_f32 turns x, dy and that norm into dx and t (12 B in, 8 B out per element; each pixel's column of t
+ * is scaled by a power of two before its fp16 split, so gradients of any magnitude keep their bits). */
+int licos_gdn_f32_fwd_norm(const float *x, const float *gamma_eff, const float *beta_eff, float *y, float *norm_out, int B, int C,
+                           int HW, int inverse, void *stream);
+int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out, int B,
+                            int C, int HW, int inverse, void *stream);
 /* NonNegativeParametrizer backward incl. CompressAI's LowerBound gradient rule. */
 int licos_reparam_bwd_f32(const float *raw, const float *d_eff, float bound, float *d_raw, long n, void *stream);
 

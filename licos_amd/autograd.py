@@ -7,6 +7,8 @@ that step that touches a tensor of the model's size is a kernel of liblicos_hip.
 backward with in-kernel reductions over the batch) and the Gaussian conditional's.  PyTorch's autograd only strings
 them together (and differentiates the scalar loss arithmetic on top).  Nothing here runs unless a gradient is required.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -158,6 +160,9 @@ class GcLikelihoodHip(torch.autograd.Function):
         return dx, (ds if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
+GDN_BWD_FUSED = os.environ.get("LICOS_GDN_BWD_FUSED", "1") != "0"  # A/B switch: the layer-by-layer backward (three-pass 1x1 products)
+
+
 class GdnHip(torch.autograd.Function):
     """GDN / IGDN with HIP forward and backward, incl. the reparametrisation chain."""
 
@@ -166,17 +171,25 @@ class GdnHip(torch.autograd.Function):
         from . import ops
         x = x.contiguous()
         beta, gamma = ops.gdn_reparam_f32(beta_raw.detach(), gamma_raw.detach(), beta_bound, gamma_bound, pedestal)
-        ctx.save_for_backward(x, beta_raw, gamma_raw, beta, gamma)
         ctx.cfg = (inverse, beta_bound, gamma_bound)
+        if GDN_BWD_FUSED and x.dim() == 4 and ops.gdn_f32_split3_applies(x.shape[1], x.shape[2] * x.shape[3]):
+            # one-pass kernels: the forward keeps norm = beta + gamma . x^2 for the backward (mfma_gdn_bwd_f32.hip)
+            y, norm = ops.gdn_f32_fwd_norm(x, gamma, beta, inverse)
+            ctx.save_for_backward(x, beta_raw, gamma_raw, beta, gamma, norm)
+            return y
+        ctx.save_for_backward(x, beta_raw, gamma_raw, beta, gamma)
         return ops.gdn_f32(x, gamma, beta, inverse)
 
     @staticmethod
     def backward(ctx, dy):
         from . import ops
-        x, beta_raw, gamma_raw, beta, gamma = ctx.saved_tensors
+        x, beta_raw, gamma_raw, beta, gamma = ctx.saved_tensors[:5]
         inverse, beta_bound, gamma_bound = ctx.cfg
         c = x.shape[1]
-        dx, t = ops.gdn_bwd_f32(x, dy.contiguous(), gamma, beta, inverse)
+        if len(ctx.saved_tensors) == 6:
+            dx, t = ops.gdn_bwd_fused_f32(x, dy.contiguous(), ctx.saved_tensors[5], gamma, inverse)
+        else:
+            dx, t = ops.gdn_bwd_f32(x, dy.contiguous(), gamma, beta, inverse)
         dbeta = dgamma = None
         if ctx.needs_input_grad[1]:
             dbeta = ops.reparam_bwd_f32(beta_raw.detach(), ops.bias_grad_f32(t), beta_bound)

@@ -284,7 +284,23 @@ int licos_gdn_f32_split3(const float *x, const float *gamma_eff, const float *be
   LICOS_REQUIRE(x && gamma_eff && beta_eff && y_blk16 && B > 0, "gdn_f32_split3: bad arguments");
   LICOS_REQUIRE(licos_gdn_f32_split3_applies(C, HW), "gdn_f32_split3: C=%d HW=%d is not served by the one-pass kernel (ask licos_gdn_f32_split3_applies)", C, HW);
   LICOS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y_blk16 & 15) == 0, "gdn_f32_split3: buffers must be 16-byte aligned");
-  return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, nullptr, y_blk16, B, HW, inverse, as_stream(stream));
+  return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, nullptr, y_blk16, nullptr, B, HW, inverse, as_stream(stream));
+}
+
+int licos_gdn_f32_fwd_norm(const float *x, const float *gamma_eff, const float *beta_eff, float *y, float *norm_out, int B, int C,
+                           int HW, int inverse, void *stream) {
+  LICOS_REQUIRE(x && gamma_eff && beta_eff && y && norm_out && B > 0, "gdn_f32_fwd_norm: bad arguments");
+  LICOS_REQUIRE(licos_gdn_f32_split3_applies(C, HW), "gdn_f32_fwd_norm: C=%d HW=%d is not served by the one-pass kernel (ask licos_gdn_f32_split3_applies)", C, HW);
+  LICOS_REQUIRE(((uintptr_t)x & 15) == 0, "gdn_f32_fwd_norm: x must be 16-byte aligned");
+  return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, nullptr, norm_out, B, HW, inverse, as_stream(stream));
+}
+
+int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out, int B,
+                            int C, int HW, int inverse, void *stream) {
+  LICOS_REQUIRE(x && dy && norm && gamma_eff && dx && t_out && B > 0, "gdn_bwd_fused_f32: bad arguments");
+  LICOS_REQUIRE(licos_gdn_f32_split3_applies(C, HW), "gdn_bwd_fused_f32: C=%d HW=%d is not served by the one-pass kernel (ask licos_gdn_f32_split3_applies)", C, HW);
+  LICOS_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)norm | (uintptr_t)t_out) & 15) == 0, "gdn_bwd_fused_f32: buffers must be 16-byte aligned");
+  return mfma_launch_gdn_bwd_f32(x, dy, norm, gamma_eff, dx, t_out, B, HW, inverse, as_stream(stream));
 }
 
 int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C, int HW,
@@ -294,7 +310,7 @@ int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff,
   // 128 channels, whole 32-pixel tiles, 16-byte aligned rows: the one-pass matrix-core kernel (mfma_gdn_f32.hip)
   static const bool use_mfma = [] { const char *e = getenv("LICOS_GDN_F32_MFMA"); return !(e && e[0] == '0'); }();
   if (use_mfma && licos_gdn_f32_split3_applies(C, HW) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
-    return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, nullptr, B, HW, inverse, as_stream(stream));
+    return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, nullptr, nullptr, B, HW, inverse, as_stream(stream));
   const size_t lds = (size_t)C * 64 * sizeof(float);
   LICOS_REQUIRE(lds <= 64 * 1024, "gdn_f32: C=%d needs %zu B of LDS (max 65536)", C, lds);
   hipLaunchKernelGGL(gdn_f32_kernel, dim3(cdiv(HW, 64), B), dim3(256), lds, as_stream(stream), x, gamma_eff, beta_eff,

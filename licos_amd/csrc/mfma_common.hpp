@@ -409,7 +409,11 @@ inline bool fewch_uses_16x16x32(int Cin, int Cout) { return Cout > 8 && Cout <= 
 int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);
 // fp32 GDN / IGDN over 128 channels on the matrix cores (mfma_gdn_f32.hip); HW must be a multiple of 32 and rows 16-byte
 // aligned.  Output: NCHW fp32 `y`, or (y_split3 != null) the 3 C-channel split operand of licos_nchw_f32_split3_blk16.
-int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, int B, long HW,
-                        int inverse, hipStream_t s);
+// norm_out (NCHW fp32 output only, nullable): beta + gamma . x^2, what the backward pass starts from.
+int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, float *norm_out,
+                        int B, long HW, int inverse, hipStream_t s);
+// GDN / IGDN backward for 128 channels in one pass (mfma_gdn_bwd_f32.hip): dx and t = dL/dnorm from x, dy and the forward's norm
+int mfma_launch_gdn_bwd_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
+                            int B, long HW, int inverse, hipStream_t s);
 
 }  // namespace licos

@@ -31,8 +31,8 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 template <bool INVERSE, bool SPLIT3>
 __global__ __launch_bounds__(512) void gdn_f32_mfma_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float *__restrict__ y,
-                                                           _Float16 *__restrict__ y3, int HW, long tiles_total,
-                                                           int tiles_per_image) {
+                                                           _Float16 *__restrict__ y3, float *__restrict__ n_out, int HW,
+                                                           long tiles_total, int tiles_per_image) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half8 *s_gam = reinterpret_cast<half8 *>(smem);                                   // [(it * 8 + ks) * 2 + part][lane]
   float *s_beta = reinterpret_cast<float *>(smem + GF_GAMMA_BYTES);                 // [128]
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(512) void gdn_f32_mfma_kernel(const float *__restri
         for (int q = 0; q < 16; ++q) {
           const int i = 32 * (2 * half + j) + (q & 3) + 8 * (q >> 2) + 4 * h;
           const float norm = acc[j][q] + accx[j][q] * (1.f / 2048.f);
+          if (!SPLIT3 && n_out) n_out[(size_t)b * GF_C * HW + p0 + p + (unsigned)(i * HW)] = norm;  // kept for the backward pass
           const float r0 = __builtin_amdgcn_rsqf(norm);
           float sc;
           if (INVERSE) {
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(512) void gdn_f32_mfma_kernel(const float *__restri
 }
 
 template <bool INVERSE, bool SPLIT3>
-static int launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, _Float16 *y3, int B, long HW,
-                          hipStream_t s) {
+static int launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, _Float16 *y3, float *n_out, int B,
+                          long HW, hipStream_t s) {
   const int tiles_per_image = (int)(HW / GF_PX);
   const long tiles_total = (long)B * tiles_per_image;
   const size_t lds = (size_t)GF_GAMMA_BYTES + (size_t)GF_C * 4 + (size_t)GF_TILES * GF_X_FLOATS * 4;
@@ -195,19 +196,19 @@ static int launch_gdn_f32(const float *x, const float *gamma_eff, const float *b
   LICOS_ENSURE_LDS(kern, lds);
   const long want = (tiles_total + GF_TILES - 1) / GF_TILES;
   const int grid = (int)(want < 256 ? want : 256);  // one 140-KB workgroup per CU, each wave pair walking its share of the tiles
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, gamma_eff, beta_eff, y, y3, (int)HW, tiles_total, tiles_per_image);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, gamma_eff, beta_eff, y, y3, n_out, (int)HW, tiles_total, tiles_per_image);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
 
-int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, int B, long HW,
-                        int inverse, hipStream_t s) {
+int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, float *norm_out,
+                        int B, long HW, int inverse, hipStream_t s) {
   LICOS_REQUIRE((long)GF_C * HW * 16 < (1L << 31), "gdn_f32: an image's plane set must stay below 2^31 bytes (32-bit offsets)");
   _Float16 *y3 = static_cast<_Float16 *>(y_split3);
-  if (y3) return inverse ? launch_gdn_f32<true, true>(x, gamma_eff, beta_eff, nullptr, y3, B, HW, s)
-                         : launch_gdn_f32<false, true>(x, gamma_eff, beta_eff, nullptr, y3, B, HW, s);
-  return inverse ? launch_gdn_f32<true, false>(x, gamma_eff, beta_eff, y, nullptr, B, HW, s)
-                 : launch_gdn_f32<false, false>(x, gamma_eff, beta_eff, y, nullptr, B, HW, s);
+  if (y3) return inverse ? launch_gdn_f32<true, true>(x, gamma_eff, beta_eff, nullptr, y3, nullptr, B, HW, s)
+                         : launch_gdn_f32<false, true>(x, gamma_eff, beta_eff, nullptr, y3, nullptr, B, HW, s);
+  return inverse ? launch_gdn_f32<true, false>(x, gamma_eff, beta_eff, y, nullptr, norm_out, B, HW, s)
+                 : launch_gdn_f32<false, false>(x, gamma_eff, beta_eff, y, nullptr, norm_out, B, HW, s);
 }
 
 }  // namespace licos

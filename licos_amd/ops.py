@@ -307,6 +307,28 @@ def gdn_f32_split3(x, gamma_eff, beta_eff, inverse=False):
     return Split3(y, c)
 
 
+def gdn_f32_fwd_norm(x, gamma_eff, beta_eff, inverse=False):
+    """(y, norm): the forward of a training step - norm = beta + gamma . x^2 is what gdn_bwd_fused_f32 starts from.
+    Shapes of gdn_f32_split3_applies only."""
+    _dev(x, gamma_eff, beta_eff)
+    b, c, h, w = x.shape
+    y, n = torch.empty_like(x), torch.empty_like(x)
+    rc = _lib.load().licos_gdn_f32_fwd_norm(_p(_f32(x)), _p(gamma_eff), _p(beta_eff), _p(y), _p(n), b, c, h * w, int(inverse), _stream())
+    _lib.check(rc, "gdn_f32_fwd_norm")
+    return y, n
+
+
+def gdn_bwd_fused_f32(x, dy, norm, gamma_eff, inverse):
+    """(dx, t) in one kernel (licos_hip.h licos_gdn_bwd_fused_f32)."""
+    _dev(x, dy, norm, gamma_eff)
+    b, c, h, w = x.shape
+    dx, t = torch.empty_like(x), torch.empty_like(x)
+    rc = _lib.load().licos_gdn_bwd_fused_f32(_p(_f32(x)), _p(_f32(dy)), _p(norm), _p(gamma_eff), _p(dx), _p(t), b, c, h * w,
+                                             int(inverse), _stream())
+    _lib.check(rc, "gdn_bwd_fused_f32")
+    return dx, t
+
+
 def gdn_f32(x, gamma_eff, beta_eff, inverse=False):
     _dev(x, gamma_eff, beta_eff)
     b, c = x.shape[:2]

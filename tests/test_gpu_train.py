@@ -149,6 +149,43 @@ def test_gdn_backward_kernel(inverse, c, scale):
         assert float((got.cpu() - want).abs().max() / want.abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("scale,gmag", [(2.0, 1.0), (300.0, 1.0), (2.0, 1e-9), (0.05, 1e-4)])
+def test_gdn_backward_one_pass_kernel(inverse, scale, gmag, monkeypatch):
+    """128 channels over whole 32-pixel tiles: forward keeps the norm, backward is ONE kernel (mfma_gdn_bwd_f32.hip:
+    t, gamma^T . t on the matrix cores with a per-pixel power-of-two scale, dx).  Against float64 autograd, for
+    activations of 0.05 .. 300 and output gradients down to 1e-9; and against the layer-by-layer backward."""
+    from licos_amd import autograd as ag
+    c = 128
+    g = torch.Generator().manual_seed(7)
+    sd = {}
+    om._gdn_init(sd, "g.", c)
+    sd["g.gamma"] = (sd["g.gamma"] + 0.05 * torch.rand(c, c, generator=g))
+    sd["g.beta"] = sd["g.beta"] * (0.5 + torch.rand(c, generator=g))
+    x = scale * torch.randn(2, c, 8, 16, generator=g)
+    go = gmag * torch.randn(2, c, 8, 16, generator=g)
+    ref_sd = {k: v.double() for k, v in sd.items()}
+    ref_sd["g.gamma"].requires_grad_(True)
+    ref_sd["g.beta"].requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    om.gdn(x64, ref_sd, "g.", inverse=inverse).backward(go.double())
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ag, "GDN_BWD_FUSED", fused)
+        m = licos_amd.GDN(c, inverse=inverse)
+        m.load_state_dict({k[2:]: v for k, v in sd.items()})
+        m = m.to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        out = m(xd)
+        out.backward(go.to(DEV))
+        grads[fused] = (xd.grad.cpu(), m.gamma.grad.cpu(), m.beta.grad.cpu())
+    for got, want in zip(grads[True], (x64.grad, ref_sd["g.gamma"].grad, ref_sd["g.beta"].grad)):
+        assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-5
+    if gmag >= 1e-4:  # (the layer-by-layer form feeds t to fp16 unscaled: below ~1e-6 its gamma^T . t underflows)
+        for a, b in zip(grads[True], grads[False]):
+            assert float((a - b).abs().max() / b.abs().max()) < 5e-5
+
+
 def test_fused_adam_and_clip_match_torch():
     from licos_amd import optimizers
     g = torch.Generator().manual_seed(1)

@@ -259,7 +259,7 @@ def extras(args, net, x, dev):
     packed, _, _ = timed_codec(net, x[:hb], 3, split=True)
     plain, _, _ = timed_codec(net, x[:hb], 3, plain=True, split=True)  # (median of 3: a host-side path, noisy on a shared box)
     out["decode_from_plain_bytes"] = {"tiles": hb, "packed": packed, "plain_list": plain}
-    # fp32 parity path (3-pass split-operand MFMA convolutions, fp32 GDN / EB)
+    # fp32 parity path (split-operand MFMA convolutions, one launch per layer; fp32 GDN / EB)
     if args.precision == "fp16":
         net.set_precision("fp32")
         chunk16 = net.chunk
@@ -267,8 +267,8 @@ def extras(args, net, x, dev):
         out["fp32_path"] = dict(timed_codec(net, x[:256].contiguous(), 3, split=True)[0], tiles=256)
         nb = min(x.shape[0], 16384)
         out["fp32_path_B%d" % nb] = dict(timed_codec(net, x[:nb], 2, split=True)[0], tiles=nb, chunk=1024,
-                                         what="the strict-parity path (three-pass split-operand MFMA transforms, fp32 GDN / EB, "
-                                              "device coder) through the same chunk pipeline")
+                                         what="the strict-parity path (one-launch split-operand MFMA transforms with the fp32 GDN in the "
+                                              "convolution's epilogue, fp32 EB, device coder) through the same chunk pipeline")
         net.chunk = chunk16
         net.set_precision("fp16")
         torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 """Chunk-pipelined encode / decode of a tile batch, either precision (fp16 MFMA transforms, or the fp32 parity path's
-three-pass split-operand transforms: the same pipeline, with fp32 NCHW activations bounded per chunk).
+split-operand transforms (fp32 accuracy on the fp16 matrix cores): the same pipeline, with fp32 NCHW activations bounded per chunk).
 
 The rANS recurrence is sequential inside a stream, so a coder launch is latency-bound: one lane per
 tile, a few waves in total, a fixed ~N_symbols x chain-latency no matter how many tiles ride along.

@@ -253,7 +253,15 @@ class ScaleHyperprior(CompressionModel):
         self.N = int(N)
         self.M = int(M)
         self.precision = precision
-        self.chunk = 512  # tiles per pipeline chunk of the large-batch codec (licos_amd/codec.py)
+        # tiles of 512 x 512 per pipeline chunk of the large-batch codec (licos_amd/codec.py); larger tiles get
+        # proportionally fewer (_chunk_for).  2048: 28 GB of 13-channel input and 34 GB of first-stage activations per
+        # chunk.  Measured at 4096 tiles of 13 x 512^2: 512 -> 10.7k, 1024 -> 11.7k, 2048 -> 12.1k, 4096 -> 12.0k tiles/s -
+        # the serial coder of a chunk does not hide under the next chunk's transforms for free (they share the CUs), so
+        # fewer, larger chunks win until the last chunk's coder tail is all that is left.
+        self.chunk = 2048
+
+    def _chunk_for(self, h, w):
+        return max(1, min(self.chunk, int(self.chunk * (512 * 512) / max(1, h * w))))
 
     @property
     def downsampling_factor(self):
@@ -277,7 +285,7 @@ class ScaleHyperprior(CompressionModel):
         self._sync_precision()
         from . import codec
         if x.shape[0] and codec.hyper_fast_path(self, x.shape[0]):
-            return codec.compress_hyper(self, x, chunk=self.chunk)
+            return codec.compress_hyper(self, x, chunk=self._chunk_for(x.shape[2], x.shape[3]))
         y = self.g_a(x)
         z = self.h_a(y)
         z_strings = self.entropy_bottleneck.compress(z)
@@ -292,7 +300,7 @@ class ScaleHyperprior(CompressionModel):
         self._sync_precision()
         from . import codec
         if len(strings[0]) and codec.hyper_fast_path(self, len(strings[0])):
-            return codec.decompress_hyper(self, strings, shape, chunk=self.chunk)
+            return codec.decompress_hyper(self, strings, shape, chunk=self._chunk_for(shape[0] * 64, shape[1] * 64))
         z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
         scales_hat = self.h_s(z_hat)
         indexes = self.gaussian_conditional.build_indexes_interleaved(scales_hat)

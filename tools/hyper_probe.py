@@ -1,5 +1,5 @@
 """Dev probe of the scale-hyperprior codec (BASELINE config 5): wall time of compress / decompress, device time of the
-serial coder launches, per-stage times.   python tools/hyper_probe.py [tiles] [chunk] [--synthetic]"""
+serial coder launches, per-stage times.   python tools/hyper_probe.py [tiles] [chunk = 2048] [--synthetic]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ import licos_amd  # noqa: E402
 from licos_amd import checkpoint, codec, engine, synthetic  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5).to(dev).eval().set_precision("fp16")

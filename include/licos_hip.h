@@ -108,6 +108,8 @@ int licos_conv2d_wgrad_f32(const float *inp /*[B][Ci][H][W]*/, const float *g /*
  * below fp16's range (1e-6 .. 1e-12) keep their bits.  scratch: licos_gdn_gamma_grad_parts(B, HW) * 128 * 128 + 4 floats. */
 int licos_gdn_gamma_grad_parts(int B, long HW);
 int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream);
+/* the same with max|t| already in the scratch's last word (written by licos_gdn_bwd_fused_f32) */
+int licos_gdn_gamma_grad_scaled_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream);
 int licos_bias_grad_f32(const float *dy /*[B][C][HW]*/, float *db /*[C]*/, int B, int C, long HW, void *stream);
 /* GDN backward: dx, and t = dL/dnorm (dgamma_eff = licos_conv2d_wgrad_f32(x, t, K=1, square_input=1), dbeta_eff =
  * licos_bias_grad_f32(t)); gamma_t_scratch: C*C floats. */
@@ -116,11 +118,13 @@ int licos_gdn_bwd_f32(const float *x, const float *dy, const float *gamma_eff, c
 /* The same backward pass for the shapes of licos_gdn_f32_split3_applies (128 channels, HW a multiple of 32) as ONE kernel on
  * the matrix cores: licos_gdn_f32_fwd_norm is licos_gdn_f32 that also writes norm = beta + gamma . x^2 (NCHW fp32),
  * licos_gdn_bwd_fused_f32 turns x, dy and that norm into dx and t (12 B in, 8 B out per element; each pixel's column of t
- * is scaled by a power of two before its fp16 split, so gradients of any magnitude keep their bits). */
+ * is scaled by a power of two before its fp16 split, so gradients of any magnitude keep their bits).  t_absmax
+ * (nullable, 4 bytes): receives the bit pattern of max|t| - pass the last word of licos_gdn_gamma_grad_f32's scratch and call
+ * licos_gdn_gamma_grad_scaled_f32, which then skips its own pass over t. */
 int licos_gdn_f32_fwd_norm(const float *x, const float *gamma_eff, const float *beta_eff, float *y, float *norm_out, int B, int C,
                            int HW, int inverse, void *stream);
-int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out, int B,
-                            int C, int HW, int inverse, void *stream);
+int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
+                            void *t_absmax, int B, int C, int HW, int inverse, void *stream);
 /* NonNegativeParametrizer backward incl. CompressAI's LowerBound gradient rule. */
 int licos_reparam_bwd_f32(const float *raw, const float *d_eff, float bound, float *d_raw, long n, void *stream);
 

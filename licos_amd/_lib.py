@@ -25,11 +25,12 @@ SIGNATURES = {
     "licos_gdn_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_gdn_f32_split3_applies": (_i, [_i, _i]),
     "licos_gdn_f32_fwd_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "licos_gdn_bwd_fused_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "licos_gdn_bwd_fused_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_gdn_f32_split3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_gdn_gamma_grad_parts": (_i, [_i, _l]),
     "licos_gdn_gamma_grad_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
+    "licos_gdn_gamma_grad_scaled_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _vp]),
     "licos_bias_grad_f32": (_i, [_vp, _vp, _i, _i, _l, _vp]),
     "licos_gdn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_reparam_bwd_f32": (_i, [_vp, _vp, _f, _vp, _l, _vp]),

@@ -186,15 +186,18 @@ class GdnHip(torch.autograd.Function):
         x, beta_raw, gamma_raw, beta, gamma = ctx.saved_tensors[:5]
         inverse, beta_bound, gamma_bound = ctx.cfg
         c = x.shape[1]
+        dg_eff = None
         if len(ctx.saved_tensors) == 6:
-            dx, t = ops.gdn_bwd_fused_f32(x, dy.contiguous(), ctx.saved_tensors[5], gamma, inverse)
+            dx, t, dg_eff = ops.gdn_bwd_fused_f32(x, dy.contiguous(), ctx.saved_tensors[5], gamma, inverse,
+                                                  want_dgamma=ctx.needs_input_grad[2] and ops.GDN_MFMA)
         else:
             dx, t = ops.gdn_bwd_f32(x, dy.contiguous(), gamma, beta, inverse)
         dbeta = dgamma = None
         if ctx.needs_input_grad[1]:
             dbeta = ops.reparam_bwd_f32(beta_raw.detach(), ops.bias_grad_f32(t), beta_bound)
         if ctx.needs_input_grad[2]:
-            dg_eff = ops.conv2d_wgrad_f32(x, t, c, c, 1, 1, 0, square_input=True).reshape(c, c)
+            if dg_eff is None:
+                dg_eff = ops.conv2d_wgrad_f32(x, t, c, c, 1, 1, 0, square_input=True).reshape(c, c)
             dgamma = ops.reparam_bwd_f32(gamma_raw.detach(), dg_eff, gamma_bound)
         return (dx if ctx.needs_input_grad[0] else None), dbeta, dgamma, None, None, None, None
 

@@ -295,12 +295,12 @@ int licos_gdn_f32_fwd_norm(const float *x, const float *gamma_eff, const float *
   return mfma_launch_gdn_f32(x, gamma_eff, beta_eff, y, nullptr, norm_out, B, HW, inverse, as_stream(stream));
 }
 
-int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out, int B,
-                            int C, int HW, int inverse, void *stream) {
+int licos_gdn_bwd_fused_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
+                            void *t_absmax, int B, int C, int HW, int inverse, void *stream) {
   LICOS_REQUIRE(x && dy && norm && gamma_eff && dx && t_out && B > 0, "gdn_bwd_fused_f32: bad arguments");
   LICOS_REQUIRE(licos_gdn_f32_split3_applies(C, HW), "gdn_bwd_fused_f32: C=%d HW=%d is not served by the one-pass kernel (ask licos_gdn_f32_split3_applies)", C, HW);
   LICOS_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)norm | (uintptr_t)t_out) & 15) == 0, "gdn_bwd_fused_f32: buffers must be 16-byte aligned");
-  return mfma_launch_gdn_bwd_f32(x, dy, norm, gamma_eff, dx, t_out, B, HW, inverse, as_stream(stream));
+  return mfma_launch_gdn_bwd_f32(x, dy, norm, gamma_eff, dx, t_out, static_cast<unsigned int *>(t_absmax), B, HW, inverse, as_stream(stream));
 }
 
 int licos_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, int B, int C, int HW,

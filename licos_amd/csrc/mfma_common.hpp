@@ -413,7 +413,8 @@ int mfma_launch_deconv_fewch(const MfmaArgs &a, hipStream_t s);
 int mfma_launch_gdn_f32(const float *x, const float *gamma_eff, const float *beta_eff, float *y, void *y_split3, float *norm_out,
                         int B, long HW, int inverse, hipStream_t s);
 // GDN / IGDN backward for 128 channels in one pass (mfma_gdn_bwd_f32.hip): dx and t = dL/dnorm from x, dy and the forward's norm
+// t_absmax (nullable): receives the bit pattern of max|t|
 int mfma_launch_gdn_bwd_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
-                            int B, long HW, int inverse, hipStream_t s);
+                            unsigned int *t_absmax, int B, long HW, int inverse, hipStream_t s);
 
 }  // namespace licos

@@ -31,8 +31,9 @@ __device__ __forceinline__ float rsqrt_newton(float n) {
 template <bool INVERSE>
 __global__ __launch_bounds__(512) void gdn_bwd_f32_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                                const float *__restrict__ nrm, const float *__restrict__ gamma,
-                                                               float *__restrict__ dx, float *__restrict__ t_out, int HW,
-                                                               long tiles_total, int tiles_per_image) {
+                                                               float *__restrict__ dx, float *__restrict__ t_out,
+                                                               unsigned int *__restrict__ t_absmax, int HW, long tiles_total,
+                                                               int tiles_per_image) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half8 *s_gam = reinterpret_cast<half8 *>(smem);  // [(it * 8 + ks) * 2 + part][lane]: 256 gamma^T, hi / lo
   const int tid = threadIdx.x, lane = tid & 63;
@@ -110,6 +111,12 @@ __global__ __launch_bounds__(512) void gdn_bwd_f32_mfma_kernel(const float *__re
 #pragma unroll
         for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(s_t[(16 * ks + 8 * h + e) * GB_RS + p]));
       m = fmaxf(m, __shfl_xor(m, 32));
+      if (t_absmax && half == 0) {  // max|t| of the whole tensor, a by-product the gamma-gradient kernel scales its operand by
+        float mt = m;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) mt = fmaxf(mt, __shfl_xor(mt, d));
+        if (lane == 0) atomicMax(t_absmax, __float_as_uint(mt));  // (bit patterns of non-negative floats order like the floats)
+      }
       int ex = (int)((__float_as_uint(m) >> 23) & 255u) - 127;  // floor(log2 m); zeros / subnormals: the smallest scale
       ex = ex < -100 ? -100 : ex;
       const float up = __uint_as_float((unsigned)(127 - ex) << 23), down = __uint_as_float((unsigned)(127 + ex) << 23) * (1.f / 256.f);
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(512) void gdn_bwd_f32_mfma_kernel(const float *__re
 }
 
 template <bool INVERSE>
-static int launch_gdn_bwd(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out, int B,
-                          long HW, hipStream_t s) {
+static int launch_gdn_bwd(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
+                          unsigned int *t_absmax, int B, long HW, hipStream_t s) {
   const int tiles_per_image = (int)(HW / GB_PX);
   const long tiles_total = (long)B * tiles_per_image;
   const size_t lds = (size_t)GB_GAMMA_BYTES + (size_t)GB_TILES * GB_T_FLOATS * 4;
@@ -171,16 +178,17 @@ static int launch_gdn_bwd(const float *x, const float *dy, const float *norm, co
   LICOS_ENSURE_LDS(kern, lds);
   const long want = (tiles_total + GB_TILES - 1) / GB_TILES;
   const int grid = (int)(want < 256 ? want : 256);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, dy, norm, gamma_eff, dx, t_out, (int)HW, tiles_total, tiles_per_image);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, dy, norm, gamma_eff, dx, t_out, t_absmax, (int)HW, tiles_total, tiles_per_image);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }
 
 int mfma_launch_gdn_bwd_f32(const float *x, const float *dy, const float *norm, const float *gamma_eff, float *dx, float *t_out,
-                            int B, long HW, int inverse, hipStream_t s) {
+                            unsigned int *t_absmax, int B, long HW, int inverse, hipStream_t s) {
   LICOS_REQUIRE((long)GB_C * HW * 16 < (1L << 31), "gdn_bwd_fused_f32: an image's plane set must stay below 2^31 bytes (32-bit offsets)");
-  return inverse ? launch_gdn_bwd<true>(x, dy, norm, gamma_eff, dx, t_out, B, HW, s)
-                 : launch_gdn_bwd<false>(x, dy, norm, gamma_eff, dx, t_out, B, HW, s);
+  if (t_absmax) LICOS_HIP_CHECK(hipMemsetAsync(t_absmax, 0, sizeof(unsigned int), s));
+  return inverse ? launch_gdn_bwd<true>(x, dy, norm, gamma_eff, dx, t_out, t_absmax, B, HW, s)
+                 : launch_gdn_bwd<false>(x, dy, norm, gamma_eff, dx, t_out, t_absmax, B, HW, s);
 }
 
 }  // namespace licos

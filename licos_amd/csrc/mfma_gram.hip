@@ -140,7 +140,17 @@ int licos_gdn_gamma_grad_parts(int B, long HW) {
   return (int)(slabs < 128 ? slabs : 128);  // enough workgroups to stream the operands, few enough partials to add cheaply
 }
 
+static int gamma_grad(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, bool absmax_ready, void *stream);
+
 int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream) {
+  return gamma_grad(t, x, scratch, dgamma, B, C, HW, false, stream);
+}
+
+int licos_gdn_gamma_grad_scaled_f32(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, void *stream) {
+  return gamma_grad(t, x, scratch, dgamma, B, C, HW, true, stream);
+}
+
+static int gamma_grad(const float *t, const float *x, float *scratch, float *dgamma, int B, int C, long HW, bool absmax_ready, void *stream) {
   LICOS_REQUIRE(t && x && scratch && dgamma && B > 0 && HW > 0, "gdn_gamma_grad_f32: bad arguments");
   LICOS_REQUIRE(C == GR_C, "gdn_gamma_grad_f32: built for 128 channels (got %d)", C);
   LICOS_REQUIRE(HW % 4 == 0 && ((uintptr_t)t & 15) == 0 && ((uintptr_t)x & 15) == 0, "gdn_gamma_grad_f32: rows must be 16-byte aligned (H*W %% 4 == 0)");
@@ -151,10 +161,12 @@ int licos_gdn_gamma_grad_f32(const float *t, const float *x, float *scratch, flo
   const int grid = (int)((slabs + per - 1) / per);
   hipStream_t s = as_stream(stream);
   unsigned int *absmax = reinterpret_cast<unsigned int *>(scratch + (size_t)parts * GR_C * GR_C);  // the scratch's last word
-  LICOS_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned int), s));
-  const long nt = (long)B * GR_C * HW;
-  hipLaunchKernelGGL(gram_absmax_kernel, dim3((int)((nt + 255) / 256 < 1024 ? (nt + 255) / 256 : 1024)), dim3(256), 0, s, t, nt, absmax);
-  LICOS_LAUNCH_CHECK();
+  if (!absmax_ready) {  // (licos_gdn_bwd_fused_f32 leaves max|t| there as a by-product: no pass over t)
+    LICOS_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned int), s));
+    const long nt = (long)B * GR_C * HW;
+    hipLaunchKernelGGL(gram_absmax_kernel, dim3((int)((nt + 255) / 256 < 1024 ? (nt + 255) / 256 : 1024)), dim3(256), 0, s, t, nt, absmax);
+    LICOS_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(gram_partial_kernel, dim3(grid), dim3(256), 0, s, t, x, scratch, absmax, B, HW, spi, per);
   LICOS_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(GR_C * GR_C / 256), dim3(256), 0, s, scratch, dgamma, grid);

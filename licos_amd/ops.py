@@ -318,15 +318,28 @@ def gdn_f32_fwd_norm(x, gamma_eff, beta_eff, inverse=False):
     return y, n
 
 
-def gdn_bwd_fused_f32(x, dy, norm, gamma_eff, inverse):
-    """(dx, t) in one kernel (licos_hip.h licos_gdn_bwd_fused_f32)."""
+def gdn_bwd_fused_f32(x, dy, norm, gamma_eff, inverse, want_dgamma=False):
+    """(dx, t, dgamma_eff or None) - dx and t in one kernel (licos_hip.h licos_gdn_bwd_fused_f32), which also leaves
+    max|t| where the gamma-gradient kernel looks for its operand scale (no extra pass over t)."""
     _dev(x, dy, norm, gamma_eff)
     b, c, h, w = x.shape
+    lib = _lib.load()
     dx, t = torch.empty_like(x), torch.empty_like(x)
-    rc = _lib.load().licos_gdn_bwd_fused_f32(_p(_f32(x)), _p(_f32(dy)), _p(norm), _p(gamma_eff), _p(dx), _p(t), b, c, h * w,
-                                             int(inverse), _stream())
+    scratch = absmax = None
+    if want_dgamma:
+        parts = lib.licos_gdn_gamma_grad_parts(b, h * w)
+        scratch = torch.empty(parts * c * c + 4, device=x.device, dtype=torch.float32)
+        absmax = scratch[parts * c * c:]
+    xc, dyc = _f32(x), _f32(dy)
+    rc = lib.licos_gdn_bwd_fused_f32(_p(xc), _p(dyc), _p(norm), _p(gamma_eff), _p(dx), _p(t), _p(absmax), b, c, h * w,
+                                     int(inverse), _stream())
     _lib.check(rc, "gdn_bwd_fused_f32")
-    return dx, t
+    dg = None
+    if want_dgamma:
+        dg = torch.empty((c, c), device=x.device, dtype=torch.float32)
+        rc = lib.licos_gdn_gamma_grad_scaled_f32(_p(t), _p(xc), _p(scratch), _p(dg), b, c, h * w, _stream())
+        _lib.check(rc, "gdn_gamma_grad_scaled_f32")
+    return dx, t, dg
 
 
 def gdn_f32(x, gamma_eff, beta_eff, inverse=False):

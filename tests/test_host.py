@@ -318,3 +318,22 @@ def test_bench_spawner_stops_all_ranks_when_one_fails():
     assert p.returncode != 0
     assert time.monotonic() - t0 < 240
     assert b"exited with status" in p.stderr and b"stderr (tail)" in p.stderr
+
+
+def test_fp32_path_shape_queries_and_argument_checks():
+    """Host-side answers of the fp32 path's C ABI (no GPU): which shapes the one-pass GDN kernels / the fp32-norm epilogue
+    serve, operand sizes, and that bad arguments come back as LICOS_EINVAL with a message instead of a launch."""
+    from licos_amd import _lib
+    lib = _lib.load()
+    assert lib.licos_gdn_f32_split3_applies(128, 64 * 64) == 1
+    assert lib.licos_gdn_f32_split3_applies(128, 33) == 0 and lib.licos_gdn_f32_split3_applies(192, 64 * 64) == 0
+    assert lib.licos_gdn_f32_split3_applies(128, 0) == 0 and lib.licos_gdn_f32_split3_applies(128, 1 << 20) == 0
+    assert lib.licos_packed_gdn_f32split_bytes(128) == 4 * 4 * 2 * 2 * 1024 + 512
+    assert lib.licos_packed_gdn_f32split_bytes(192) == 0 and lib.licos_packed_gdn_f32split_bytes(0) == 0
+    for call in (lambda: lib.licos_gdn_f32_split3(None, None, None, None, 1, 128, 4096, 0, None),
+                 lambda: lib.licos_gdn_bwd_fused_f32(None, None, None, None, None, None, None, 1, 128, 4096, 0, None),
+                 lambda: lib.licos_gdn_f32_fwd_norm(None, None, None, None, None, 1, 128, 4096, 0, None),
+                 lambda: lib.licos_nchw_f32_split3_blk16(None, None, 1, 3, 8, 8, 0, None),
+                 lambda: lib.licos_pack_gdn_f32split(None, None, 0.0, 0.0, 0.0, 128, None, None)):
+        assert call() == -1  # LICOS_EINVAL
+        assert lib.licos_last_error()

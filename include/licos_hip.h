@@ -398,6 +398,17 @@ int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scat
                                   int clamp01 /* bit 0: clamp to [0,1]; bit 1: x is x-split (LICOS_EPI_IN_XSPLIT) */, int B,
                                   int Cin, int H, int W, int Cout, void *stream);
 
+/* The same stage for 1..3 output channels in row-walking form (the fp16 path's default for RGB / single-band tiles):
+ * Z[(py, kx, c)][y][x] = sum over (dy, cin) as ONE 32-row MFMA tile per 32 input pixels, B operands = the fragments of input
+ * rows y-1, y, y+1 held in registers while a wave walks down its 32-column strip (every input row is read once per
+ * row block), the x shift out[.., 2x + px] = sum_kx Z[..kx..][x + (px + 2 - kx) / 2] through LDS between neighbouring lanes.
+ * fp32 sums in a fixed order.  CompressAI FactorizedPrior.g_s[6] as licos/model_utils.py:38-45 re-sizes it (3 / 1 bands). */
+size_t licos_packed_deconv_w_rows_bytes(int Cin, int Cout);
+int licos_pack_deconv_w_rows_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_deconv5x5s2_rows_f16(const void *x_blk16, const void *w_packed_rows, const float *bias, float *y_nchw,
+                               int clamp01 /* bit 0: clamp to [0,1]; bit 1: x is x-split (LICOS_EPI_IN_XSPLIT) */, int B,
+                               int Cin, int H, int W, int Cout, void *stream);
+
 /* 1x1 convolution on the matrix cores, NCHW fp32 output: the channel product of GDN / IGDN ([CAI] layers/gdn.py:
  * norm = conv2d(x^2, gamma, beta)) and of its backward pass (gamma^T . t), as three split-operand passes (`epilogue` =
  * LICOS_EPI_NONE, then LICOS_EPI_ACCUMULATE | LICOS_EPI_SCALE_DOWN(k)).  w: [Cout][Cin] fp32 row-major.  Instantiated

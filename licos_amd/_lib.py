@@ -90,6 +90,9 @@ SIGNATURES = {
     "licos_packed_deconv_w_scatter_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_deconv_w_scatter_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_deconv5x5s2_scatter_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "licos_packed_deconv_w_rows_bytes": (_c.c_size_t, [_i, _i]),
+    "licos_pack_deconv_w_rows_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "licos_deconv5x5s2_rows_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_nchw_f32_to_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_packed_conv1x1_w_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_conv1x1_w_f16": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -43,6 +43,7 @@ def _pver(p):
 
 
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
+ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
 
 
 def _packed_conv(m, s2d=False, fewch=False):
@@ -56,7 +57,9 @@ def _packed_conv(m, s2d=False, fewch=False):
             raise ValueError("licos_amd: the fp16 MFMA path implements 5x5 stride-2 (de)convolutions and 3x3 "
                              "stride-1 convolutions; use precision='fp32' for other shapes")
         cout = m.out_channels
-        if fewch == "scatter":
+        if fewch == "rows":
+            wp = ops.pack_deconv_w_rows_f16(m.weight.detach())
+        elif fewch == "scatter":
             wp = ops.pack_deconv_w_scatter_f16(m.weight.detach())
         elif fewch:
             wp = ops.pack_deconv_w_fewch_f16(m.weight.detach())
@@ -148,12 +151,13 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         last = idx == len(st) - 1
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
         if scatter_last(idx):
-            fewch = "scatter"
+            fewch = "rows" if (ROWS_LAST and m.out_channels <= 3) else "scatter"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
-        if fewch == "scatter":
+        if fewch in ("rows", "scatter"):
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], False)
-            cur = _timed(key, lambda: ops.deconv5x5s2_scatter_f16(cur, wp, bp, m.in_channels, m.out_channels,
-                                                                  clamp01=clamp01, out=out, in_xsplit=xsplit))
+            last_op = ops.deconv5x5s2_rows_f16 if fewch == "rows" else ops.deconv5x5s2_scatter_f16
+            cur = _timed(key, lambda: last_op(cur, wp, bp, m.in_channels, m.out_channels,
+                                              clamp01=clamp01, out=out, in_xsplit=xsplit))
             xsplit = False  # NCHW fp32 from here
             continue
         if fewch:

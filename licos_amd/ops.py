@@ -1051,6 +1051,30 @@ def deconv5x5s2_scatter_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out
     _lib.check(rc, "deconv5x5s2_scatter_f16")
     return y
 
+def pack_deconv_w_rows_f16(w):
+    _dev(w)
+    cin, cout = w.shape[:2]
+    nbytes = _lib.load().licos_packed_deconv_w_rows_bytes(cin, cout)
+    if nbytes == 0:
+        raise ValueError(f"licos_amd: row-walking deconv supports 1..3 output channels, got {cout}")
+    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_pack_deconv_w_rows_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
+               "pack_deconv_w_rows_f16")
+    return packed
+
+
+def deconv5x5s2_rows_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=None, in_xsplit=False):
+    """Last synthesis stage, 1..3 output channels, row-walking form (csrc/mfma_rows.hip): NCHW fp32 out."""
+    _dev(x_blk, w_packed, bias, out)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("deconv5x5s2_rows_f16: input is not the blk16 fp16 layout of `cin` channels")
+    y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
+    rc = _lib.load().licos_deconv5x5s2_rows_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
+                                                b, cin, h, w, cout, _stream())
+    _lib.check(rc, "deconv5x5s2_rows_f16")
+    return y
+
 
 def pack_conv3x3_w_f16(w):
     _dev(w)

@@ -247,6 +247,57 @@ def test_scatter_deconv_rejects_unsupported_shapes():
         ops.deconv5x5s2_scatter_f16(xb, ws, torch.zeros(3, device=DEV), 64, 3)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 32, 32), (128, 1, 16, 16), (128, 3, 128, 128), (128, 2, 9, 40), (128, 3, 20, 36),
+                                           (192, 3, 8, 33), (192, 1, 5, 3), (128, 3, 1, 1), (128, 3, 7, 130), (128, 1, 4, 300),
+                                           (128, 3, 37, 128)])
+def test_rows_deconv_exact_operands(cin, cout, h, w):
+    """Row-walking last stage (csrc/mfma_rows.hip): same operands as torch-CPU conv_transpose2d, fp32 sums: ragged widths
+    (dead lanes read zeros through the buffer bounds), maps wider than one 128-column strip (126 live columns per strip),
+    row blocks that end inside a turn of the register ring, 1..3 bands, both channel counts."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = h16(torch.randn(2, cin, h, w, generator=g))
+    wt = h16(torch.randn(cin, cout, 5, 5, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=2, output_padding=1).float()
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    ws = ops.pack_deconv_w_rows_f16(wt.to(DEV))
+    bd = b.to(DEV)
+    out = ops.deconv5x5s2_rows_f16(xb, ws, bd, cin, cout)
+    assert out.shape == ref.shape
+    assert float((out.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    outc = ops.deconv5x5s2_rows_f16(xb, ws, bd, cin, cout, clamp01=True)
+    assert float((outc.cpu() - ref.clamp(0, 1)).abs().max()) < 4e-5
+    assert torch.equal(ops.deconv5x5s2_rows_f16(xb, ws, bd, cin, cout), out)
+    if w % 2 == 0:  # the x-split input layout is a pure re-ordering
+        assert torch.equal(ops.deconv5x5s2_rows_f16(ops.blk16_xsplit(xb), ws, bd, cin, cout, in_xsplit=True), out)
+    # against the scatter form (2^-20 fixed-point sums of the same products)
+    sc = ops.deconv5x5s2_scatter_f16(xb, ops.pack_deconv_w_scatter_f16(wt.to(DEV)), bd, cin, cout)
+    assert float((sc - out).abs().max()) < 9 * 2.0 ** -21 + 2e-5 * float(ref.abs().max())
+
+
+def test_rows_deconv_is_batch_and_block_invariant():
+    """A tile's output bits do not depend on the batch it runs in (large batches walk 32-row blocks, small ones 8-row
+    blocks): the per-pixel sum order is the same in both."""
+    g = torch.Generator().manual_seed(5)
+    x = h16(torch.randn(40, 128, 64, 64, generator=g))  # 40 x 2 row blocks of 32 < 2048 -> 8-row blocks ...
+    wt = h16(torch.randn(128, 3, 5, 5, generator=g) * 0.05)
+    b = torch.randn(3, generator=g).to(DEV)
+    ws = ops.pack_deconv_w_rows_f16(wt.to(DEV))
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    one = ops.deconv5x5s2_rows_f16(xb[:1].contiguous(), ws, b, 128, 3)
+    big = ops.deconv5x5s2_rows_f16(xb.repeat(64, 1, 1, 1, 1), ws, b, 128, 3)  # ... 2560 x 2 >= 2048 -> 32-row blocks
+    assert torch.equal(big[:1], one) and torch.equal(big[40:41], one)
+
+
+def test_rows_deconv_rejects_unsupported_shapes():
+    with pytest.raises(ValueError):
+        ops.pack_deconv_w_rows_f16(torch.zeros(128, 4, 5, 5, device=DEV))
+    xb = torch.zeros(1, 4, 8, 8, 16, device=DEV, dtype=torch.float16)  # 64 input channels: not instantiated
+    ws = ops.pack_deconv_w_rows_f16(torch.zeros(64, 3, 5, 5, device=DEV))
+    with pytest.raises(ValueError):
+        ops.deconv5x5s2_rows_f16(xb, ws, torch.zeros(3, device=DEV), 64, 3)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("h,w", [(64, 64), (32, 32)])
 def test_fused_gdn_epilogue(inverse, h, w):

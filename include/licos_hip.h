@@ -382,6 +382,18 @@ int licos_conv5x5s2_s2d_f16(const void *x_s2d_blk16, const void *w_packed_s2d, c
                             const void *gdn_packed, int epilogue, void *y_blk16, float *y_nchw, int B, int Cin,
                             int H, int W, int Cout, void *stream);
 
+/* First analysis stage for 1..3 input bands and <= 128 output channels (the fp16 path's default for RGB / single-band
+ * tiles): K steps = kernel rows (ky; kx, c) over an interleaved, zero-bordered fp16 image
+ * [B][H + 4][round_up((W + 4) C + 8, 8)] that licos_nchw_f32_to_hwc_pad_f16 writes (value (c, iy, ix) at half
+ * (iy + 2) * row + (ix + 2) * C + c); two independent 4-wave workgroups per CU; output blk16 fp16, epilogue
+ * LICOS_EPI_NONE / _GDN / _RELU.  CompressAI FactorizedPrior.g_a[0] (+ GDN g_a[1]) as licos/model_utils.py:31-37 re-sizes it. */
+size_t licos_hwc_pad_f16_bytes(int B, int C, int H, int W);
+int licos_nchw_f32_to_hwc_pad_f16(const float *x_nchw, void *x_hwc_pad, int B, int C, int H, int W, void *stream);
+size_t licos_packed_conv_w_first_bytes(int Cin, int Cout);
+int licos_pack_conv_w_first_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
+int licos_conv5x5s2_first_f16(const void *x_hwc_pad, const void *w_packed_first, const float *bias, const void *gdn_packed,
+                              int epilogue, void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream);
+
 /* Last synthesis stage (Cout <= 32, NCHW fp32 out): all four output phases per workgroup, weights stored compact
  * (only ceil-pow2(Cout) rows per fragment).  CompressAI FactorizedPrior.g_s[6], replaced per licos/model_utils.py:38-45. */
 size_t licos_packed_deconv_w_fewch_bytes(int Cin, int Cout);

@@ -84,6 +84,11 @@ SIGNATURES = {
     "licos_nchw_f32_to_s2d_blk16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_pack_conv_w_s2d_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_conv5x5s2_s2d_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_hwc_pad_f16_bytes": (_c.c_size_t, [_i, _i, _i, _i]),
+    "licos_nchw_f32_to_hwc_pad_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "licos_packed_conv_w_first_bytes": (_c.c_size_t, [_i, _i]),
+    "licos_pack_conv_w_first_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "licos_conv5x5s2_first_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_packed_deconv_w_fewch_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_deconv_w_fewch_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_deconv5x5s2_fewch_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -16,6 +16,9 @@
 #ifndef LICOS_STORE_SC1
 #define LICOS_STORE_SC1 1
 #endif
+#ifndef LICOS_STORE_BITS  // (A/B builds: the cache-policy bits of that store, as assembler text)
+#define LICOS_STORE_BITS "sc1"
+#endif
 
 namespace licos {
 
@@ -163,7 +166,7 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
             // (the s_nop covers the ISA's manual wait state between a store of more than 64 bits and the next write of
             // its data registers, which the compiler cannot see through the asm)
             const unsigned off = pix_off[nt] + (unsigned)chunk * chunk_bytes;
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(val), "s"(y_base) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2 " LICOS_STORE_BITS "\n\ts_nop 1" ::"v"(off), "v"(val), "s"(y_base) : "memory");
           } else {
             _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
             *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);

@@ -43,11 +43,12 @@ def _pver(p):
 
 
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
+FIRST_ROWS = os.environ.get("LICOS_FIRST", "1") != "0"  # kernel-row first stage (1..3 bands) instead of the space-to-depth 3x3 form
 ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
 
 
-def _packed_conv(m, s2d=False, fewch=False):
-    key = (_pver(m.weight), _pver(m.bias), s2d, fewch)
+def _packed_conv(m, s2d=False, fewch=False, first=False):
+    key = (_pver(m.weight), _pver(m.bias), s2d, fewch, first)
     ent = _cache.get(m)
     if ent is None or ent[0] != key:
         transposed = isinstance(m, nn.ConvTranspose2d)
@@ -57,7 +58,9 @@ def _packed_conv(m, s2d=False, fewch=False):
             raise ValueError("licos_amd: the fp16 MFMA path implements 5x5 stride-2 (de)convolutions and 3x3 "
                              "stride-1 convolutions; use precision='fp32' for other shapes")
         cout = m.out_channels
-        if fewch == "rows":
+        if first:
+            wp = ops.pack_conv_w_first_f16(m.weight.detach())
+        elif fewch == "rows":
             wp = ops.pack_deconv_w_rows_f16(m.weight.detach())
         elif fewch == "scatter":
             wp = ops.pack_deconv_w_scatter_f16(m.weight.detach())
@@ -126,8 +129,18 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         s2d_first = (isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
                      and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in
                      and x.shape[1] <= 4 and h0 % 2 == 0 and w0 % 2 == 0)
-        cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
+        # 1..3 bands into <= 128 channels: K steps = kernel rows over the interleaved image (csrc/mfma_first.hip)
+        first_rows = (FIRST_ROWS and isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
+                      and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in and x.shape[1] <= 3
+                      and st[0][0].out_channels <= 128 and len(st) > 1 and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse)
+                      and min(h0, w0) >= 16)
+        if first_rows:
+            s2d_first = False
+            cur = ops.nchw_f32_to_hwc_pad_f16(x.contiguous())
+        else:
+            cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
     else:
+        first_rows = False
         cur = x_blk
     xsplit = False  # layout of `cur`: blk16, or its x-split form (ops.EPI_OUT_XSPLIT) between two kernels that agree on it
 
@@ -152,7 +165,7 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
         if scatter_last(idx):
             fewch = "rows" if (ROWS_LAST and m.out_channels <= 3) else "scatter"
-        wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch)
+        wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch, first=(first_rows and idx == 0))
         if fewch in ("rows", "scatter"):
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], False)
             last_op = ops.deconv5x5s2_rows_f16 if fewch == "rows" else ops.deconv5x5s2_scatter_f16
@@ -168,6 +181,10 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         gp = _packed_gdn(g) if isinstance(g, GDN) else None
         epi = ops.EPI_NONE if g is None else ops.EPI_RELU if g == "relu" else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
         norm = gp is not None
+        if first_rows and idx == 0:
+            key = ("conv", m.in_channels, m.out_channels, h0, w0, x.shape[0], norm)
+            cur = _timed(key, lambda: ops.conv5x5s2_first_f16(cur, wp, bp, gp, epi, x.shape[0], m.in_channels, m.out_channels, h0, w0))
+            continue
         if s2d_first and idx == 0:
             key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0], norm)
             cur = _timed(key, lambda: ops.conv5x5s2_s2d_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels, h0, w0,

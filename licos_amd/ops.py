@@ -1004,6 +1004,44 @@ def conv5x5s2_s2d_f16(x_s2d, w_packed, bias_padded, gdn_packed, epilogue, cin, c
     return y
 
 
+def nchw_f32_to_hwc_pad_f16(x):
+    """NCHW fp32 (1..3 bands) -> the interleaved, zero-bordered fp16 image of the first analysis stage (csrc/mfma_first.hip);
+    returns a flat fp16 buffer (with the slack the kernel's edge tiles may touch)."""
+    _dev(x)
+    b, c, h, w = x.shape
+    nbytes = _lib.load().licos_hwc_pad_f16_bytes(b, c, h, w)
+    if nbytes == 0:
+        raise ValueError(f"licos_amd: the interleaved first-stage image supports 1..3 bands, got {c}")
+    y = torch.empty(nbytes // 2, device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_nchw_f32_to_hwc_pad_f16(_p(_f32(x)), _p(y), b, c, h, w, _stream()), "nchw_f32_to_hwc_pad_f16")
+    return y
+
+
+def pack_conv_w_first_f16(w):
+    _dev(w)
+    cout, cin = w.shape[:2]
+    nbytes = _lib.load().licos_packed_conv_w_first_bytes(cin, cout)
+    if nbytes == 0 or tuple(w.shape[2:]) != (5, 5):
+        raise ValueError(f"licos_amd: the first-stage kernel takes 1..3 input and <= 128 output channels, 5x5; got {tuple(w.shape)}")
+    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    _lib.check(_lib.load().licos_pack_conv_w_first_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
+               "pack_conv_w_first_f16")
+    return packed
+
+
+def conv5x5s2_first_f16(x_hwc, w_packed, bias_padded, gdn_packed, epilogue, b, cin, cout, h, w):
+    """b, h, w: batch and ORIGINAL image size of the NCHW tensor `x_hwc` was made from; returns blk16 fp16."""
+    _dev(x_hwc, w_packed, bias_padded, gdn_packed)
+    if x_hwc.dtype != torch.float16 or x_hwc.numel() * 2 < _lib.load().licos_hwc_pad_f16_bytes(b, cin, h, w):
+        raise ValueError("conv5x5s2_first_f16: input is not the buffer nchw_f32_to_hwc_pad_f16 makes for this shape")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_hwc.device, dtype=torch.float16)
+    rc = _lib.load().licos_conv5x5s2_first_f16(_p(x_hwc), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
+                                               b, cin, h, w, cout, _stream())
+    _lib.check(rc, "conv5x5s2_first_f16")
+    return y
+
+
 def pack_deconv_w_fewch_f16(w):
     _dev(w)
     cin, cout = w.shape[:2]

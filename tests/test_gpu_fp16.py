@@ -535,6 +535,65 @@ def test_first_stage_space_to_depth_equals_conv(cin, h, w):
     assert rel_err(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,h,w,epi", [(3, 128, 64, 64, "none"), (1, 128, 32, 48, "none"), (3, 128, 256, 256, "gdn"),
+                                               (2, 128, 18, 70, "relu"), (3, 96, 16, 16, "none"), (3, 128, 50, 130, "gdn"),
+                                               (1, 128, 256, 256, "gdn"), (3, 128, 37, 65, "none")])
+def test_first_stage_kernel_rows_equals_conv(cin, cout, h, w, epi):
+    """First analysis stage with K steps = kernel rows over the interleaved zero-bordered fp16 image (csrc/mfma_first.hip,
+    two 4-wave workgroups per CU): same operands as torch-CPU conv2d; ragged tiles, odd sizes, 1..3 bands, every epilogue;
+    identical to the space-to-depth form up to the fp32 summation order."""
+    from licos_amd.layers import GDN
+    g = torch.Generator().manual_seed(cin * 7 + h)
+    x = h16(torch.rand(3, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 5, 5, generator=g) * 0.2)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=2).float()
+    xi = ops.nchw_f32_to_hwc_pad_f16(x.to(DEV))
+    rs = ((w + 4) * cin + 8 + 7) // 8 * 8
+    img = xi[: 3 * (h + 4) * rs].view(3, h + 4, rs).float().cpu()
+    want = torch.zeros(3, h + 4, rs)
+    want[:, 2:h + 2, 2 * cin:(w + 2) * cin] = x.permute(0, 2, 3, 1).reshape(3, h, w * cin)
+    assert torch.equal(img, want)  # interleaved, 2-pixel zero border, zero row tail
+    wp = ops.pack_conv_w_first_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    gp, e, tol = None, ops.EPI_NONE, 2e-3  # fp16 output
+    if epi == "gdn":
+        sd = {}
+        om._gdn_init(sd, "g.", cout)
+        sd["g.gamma"] = sd["g.gamma"] + 0.03 * torch.rand(cout, cout, generator=g)
+        m = GDN(cout)
+        m.load_state_dict({k[2:]: v for k, v in sd.items()})
+        gp, e, tol = engine._packed_gdn(m.to(DEV)), ops.EPI_GDN, 4e-3
+        ref = om.gdn(ref, sd, "g.")
+    elif epi == "relu":
+        e, ref = ops.EPI_RELU, ref.clamp_min(0)
+    out = ops.conv5x5s2_first_f16(xi, wp, bp, gp, e, 3, cin, cout, h, w)
+    got = ops.blk16_to_nchw_f32(out, cout)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < tol
+    assert torch.equal(ops.conv5x5s2_first_f16(xi, wp, bp, gp, e, 3, cin, cout, h, w), out)
+    if h % 2 == 0 and w % 2 == 0 and min(h, w) >= 32 and cout == 128:  # against the 3x3 form on the same operands
+        xs = ops.nchw_f32_to_s2d_blk16(x.to(DEV))
+        old = ops.conv5x5s2_s2d_f16(xs, ops.pack_conv_w_s2d_f16(wt.to(DEV)), bp, gp, e, cin, cout, h, w)
+        assert rel_err(ops.blk16_to_nchw_f32(old, cout), got) < tol
+    # a tile's bits do not depend on the batch it is in
+    one = ops.conv5x5s2_first_f16(ops.nchw_f32_to_hwc_pad_f16(x[2:3].to(DEV)), wp, bp, gp, e, 1, cin, cout, h, w)
+    assert torch.equal(one, out[2:3])
+
+
+def test_first_stage_kernel_rows_rejects_unsupported_shapes():
+    with pytest.raises(ValueError):
+        ops.pack_conv_w_first_f16(torch.zeros(128, 4, 5, 5, device=DEV))
+    with pytest.raises(ValueError):
+        ops.pack_conv_w_first_f16(torch.zeros(192, 3, 5, 5, device=DEV))
+    with pytest.raises(ValueError):
+        ops.nchw_f32_to_hwc_pad_f16(torch.zeros(1, 4, 16, 16, device=DEV))
+    xi = ops.nchw_f32_to_hwc_pad_f16(torch.zeros(1, 3, 16, 16, device=DEV))
+    wp = ops.pack_conv_w_first_f16(torch.zeros(128, 3, 5, 5, device=DEV))
+    with pytest.raises(ValueError):  # a buffer made for a smaller shape
+        ops.conv5x5s2_first_f16(xi, wp, torch.zeros(128, device=DEV), None, ops.EPI_NONE, 1, 3, 128, 64, 64)
+
+
 def _relu_state(cin, seed):
     """A factorized-relu state: the factorized state without the GDN entries."""
     sd = om.perturb_state(om.make_factorized_state(cin, quality=1, seed=42), seed=seed, y_gain=20.0)

@@ -148,6 +148,28 @@ def stage_flops(kind, cin, cout, h, w, norm=False):
     return 2.0 * pix_out * (taps * cin * cout + (cout * cout if norm else 0))
 
 
+PEAK_HBM_TBPS = 8.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s measured with a float4 copy)
+
+
+def stage_entry(key, ms, launches):
+    """One `stages` entry.  The two end stages move bytes, not FLOPs (the first: 4 MiB of fp16 out per 256^2 tile for 0.5
+    GFLOP; the last: 4 MiB in for 0.3 GFLOP): they are priced against the HBM roof - algorithmic bytes = input read once +
+    output written once, in the dtypes the kernels use (fp32 image side, fp16 blk16 activations) - the others against the
+    MFMA roof."""
+    kind, cin, cout, h, w, b, norm = key[:7]
+    fl = stage_flops(kind, cin, cout, h, w, norm=norm) * b
+    ent = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": launches, "bound": "mfma"}
+    few_in, few_out = kind == "conv" and cin <= 16, kind == "deconv" and cout <= 16
+    if few_in or few_out:
+        if few_in:
+            nbytes = (cin * h * w * 4 + cout * (h // 2) * (w // 2) * 2) * b
+        else:
+            nbytes = (cin * h * w * 2 + cout * (2 * h) * (2 * w) * 4) * b
+        ent.update({"bound": "hbm", "GBps": round(nbytes / ms / 1e6, 1), "frac_hbm": round(nbytes / ms / 1e9 / PEAK_HBM_TBPS, 4),
+                    "algorithmic_bytes_per_launch": nbytes})
+    return ent
+
+
 def quality_match(net, sd, x8):
     """bpp / PSNR of the GPU fp16 path vs the CPU oracle on the same 8 tiles (the "matched" of the metric)."""
     import torch
@@ -350,7 +372,7 @@ def hyperprior_grid(args, dev):
                 ms_all = [e0.elapsed_time(e1) for e0, e1 in evs]
                 ms = sum(ms_all) / len(ms_all)
                 fl = stage_flops(*key[:5], norm=key[6]) * key[5]
-                stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
+                stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = stage_entry(key, ms, len(evs))
                 if key[1] >= 128 and key[2] >= 128 and (dom is None or sum(ms_all) > dom[1]):
                     dom = (key, sum(ms_all), ms, fl)
             res["stages"] = stages
@@ -510,8 +532,7 @@ def main():
         for key, evs in events.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
             per_stage_ms[key] = ms
-            fl = stage_flops(*key[:5], norm=key[6]) * key[5]
-            stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "launches": len(evs)}
+            stages["%s_%d_%d_%dx%d_b%d" % key[:6]] = stage_entry(key, ms, len(evs))
 
         def roofline_of(key, kernel_name, traffic_file):
             LB = key[5]

@@ -393,6 +393,10 @@ size_t licos_packed_conv_w_first_bytes(int Cin, int Cout);
 int licos_pack_conv_w_first_f16(const float *w /*[Cout][Cin][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_conv5x5s2_first_f16(const void *x_hwc_pad, const void *w_packed_first, const float *bias, const void *gdn_packed,
                               int epilogue, void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream);
+/* The same stage on the NCHW fp32 image IN PLACE (W a multiple of 4): the fp32 rows arrive by LDS-DMA, zero padding is a
+ * per-granule source choice, the workgroup interleaves and converts them LDS to LDS - no layout pass, bit-identical output. */
+int licos_conv5x5s2_first_nchw_f16(const float *x_nchw, const void *w_packed_first, const float *bias, const void *gdn_packed,
+                                   int epilogue, void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream);
 
 /* Last synthesis stage (Cout <= 32, NCHW fp32 out): all four output phases per workgroup, weights stored compact
  * (only ceil-pow2(Cout) rows per fragment).  CompressAI FactorizedPrior.g_s[6], replaced per licos/model_utils.py:38-45. */

@@ -20,11 +20,6 @@
 
 #include "mfma_deconv8.hpp"
 
-// A/B builds only (tools/ab_build.sh): 1 = the epilogue at raised issue priority, 2 = the K loop
-#ifndef LICOS_FIRST_PRIO
-#define LICOS_FIRST_PRIO 0
-#endif
-
 namespace licos {
 
 struct FirstArgs {
@@ -34,7 +29,6 @@ struct FirstArgs {
   const bf16x8 *gamma;
   _Float16 *y_blk;
   int B, H, W, Ho, Wo, Cout, tiles_x, tiles_y, rsg;  // rsg: halfs per padded input row (a multiple of 8)
-  int skew;            // start delay of the second workgroup of every CU, in units of 1024 cycles
 };
 
 __host__ __device__ constexpr int first_row_halfs(int W, int C) { return ((W + 4) * C + 8 + 7) / 8 * 8; }
@@ -125,12 +119,6 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_kernel(FirstArgs a, in
       }
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // Two workgroups that start together on a CU stay in step for the whole launch (same work, same durations; their
-  // successors start together again): K loops beside K loops, epilogues beside epilogues.  The workgroups that fill the
-  // CUs' SECOND slots at launch (linear ids 256 .. 511: the dispatcher deals ids round-robin over XCDs, then CUs) start
-  // half a tile late; the offset carries over to every later pair.
-  if (blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(16);
   __builtin_amdgcn_s_barrier();
   acc_init();
   if (t_count > 1) dma_patch(1, 1);  // tile 1's patch lands under tile 0's MFMAs
@@ -143,7 +131,6 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_kernel(FirstArgs a, in
   for (int t = 0; t < t_count; ++t) {
     const int cur = t & 1;
     const unsigned char *pb = reinterpret_cast<const unsigned char *>(s_pbuf + cur * G::PATCH_PAD) + lane_boff;
-    if (LICOS_FIRST_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
       half8 bf[NT];
@@ -164,11 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_kernel(FirstArgs a, in
     }
     // the patch of tile t+1 (requested before the previous epilogue, or above) has landed: everything older than this
     // wave's last NSTORE operations is complete
-    if (LICOS_FIRST_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (LICOS_FIRST_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if (t + 2 < t_count) dma_patch(t + 2, cur);  // buffer `cur` is free now
     asm volatile("" ::: "memory");               // the stores below stay behind that request
     const int tile = t_first + t;
@@ -184,7 +169,209 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_kernel(FirstArgs a, in
     tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, y_img, (size_t)a.Ho * a.Wo, Cout16, pix, lane);
     counted = all_live;
     if (t + 1 < t_count) acc_init();
-    if (LICOS_FIRST_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+// ---- the same stage reading the NCHW fp32 image in place (no layout pass) ----------------------------------------------
+// The fp32 rows of a tile arrive by LDS-DMA as they lie in memory - per band and input row 18 granules of 4 pixels,
+// columns 2 tx0 - 4 .. 2 tx0 + 67; with W a multiple of 4 and tile origins multiples of 64 a granule is entirely inside
+// the image or entirely outside it, so zero padding is a per-granule choice of source address (16 zero bytes ride at the
+// end of the packed weights) - and the workgroup turns them into the interleaved fp16 patch itself, LDS to LDS: a thread
+// takes the C bands' granules of a 4-pixel group (16-byte reads) and writes their 4 C interleaved halfs as 2 C dwords,
+// one or two groups per tile, between the K loop and the epilogue.  One raw
+// buffer and one patch buffer (78 KB per workgroup: still two per CU):
+//   K loop (patch) | wait: raw rows of tile t+1 landed | barrier | repack raw -> patch | barrier | request raw rows of
+//   tile t+2 | epilogue of tile t, stores
+struct FirstRawArgs {
+  const float *x;      // NCHW fp32 [B][C][H][W]
+  const half8 *wp;     // [5 ky][MT][64] A fragments + one granule of zeros
+  const float *bias, *beta;
+  const bf16x8 *gamma;
+  _Float16 *y_blk;
+  int B, H, W, Ho, Wo, Cout, tiles_x, tiles_y;
+};
+
+template <int C>
+struct FirstRawGeom {
+  using G = FirstGeom<C>;
+  static constexpr int SG = 18;                       // fp32 granules per (band, input row)
+  static constexpr int SGT = C * G::PR * SG;          // granules of a tile's raw rows (1026 at C = 3)
+  static constexpr int SQ = (SGT + 63) / 64, S_PAD = SQ * 64, NSP = (SQ + 3) / 4;  // wave-wide DMA pieces; per wave
+  static_assert(4 * SG - 2 >= 2 * G::TW + 3, "18 granules cover the 67 input columns of a tile");
+};
+
+template <int C, int EPI>
+__global__ __launch_bounds__(256, 2) void conv5x5s2_first_raw_kernel(FirstRawArgs a, int run) {
+  using G = FirstGeom<C>;
+  using R = FirstRawGeom<C>;
+  constexpr int MT = G::MT, NT = G::NT;
+  constexpr bool NORM = (EPI == EPI_GDN);
+  constexpr int NSTORE = NT * MT * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_raw = reinterpret_cast<half8 *>(smem);  // [S_PAD] granules of 4 fp32 pixels
+  half8 *s_p = s_raw + R::S_PAD;                    // [PATCH_PAD] the interleaved fp16 patch
+  half8 *s_w = s_p + G::PATCH_PAD;                  // [5 MT 64] resident
+  float *s_bias = reinterpret_cast<float *>(s_w + G::W_GRAN);
+  float *s_beta = s_bias + 32 * MT;
+  bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(s_beta + 32 * MT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y, runs = (tiles + run - 1) / run;
+  int b, item;
+  xcd_work_item(blockIdx.x, a.B, runs, b, item);
+  const int t_first = item * run, t_count = (t_first + run <= tiles) ? run : tiles - t_first;
+  const float *xb = a.x + (size_t)b * C * a.H * a.W;
+  const half8 *zero = a.wp + G::W_GRAN;
+
+  // my granules to request: idx = tid + 256 i -> (band, patch row, granule of 4 columns)
+  int g_rel[R::NSP], g_rc[R::NSP];
+#pragma unroll
+  for (int i = 0; i < R::NSP; ++i) {
+    int idx = tid + 256 * i;
+    idx = idx < R::SGT ? idx : R::SGT - 1;  // (the tail of the last piece repeats the last granule)
+    const int c = idx / (G::PR * R::SG), rem = idx - c * (G::PR * R::SG);
+    const int prow = rem / R::SG, g = rem - prow * R::SG;
+    g_rel[i] = (c * a.H + prow) * a.W + 4 * g;  // element offset from (row 2 ty0 - 2, column 2 tx0 - 4) of band 0
+    g_rc[i] = prow | (4 * g) << 8;
+  }
+  auto dma_raw = [&](int t) {
+    const int tile = t_first + t;
+    const int iy0 = 2 * (tile / a.tiles_x) * G::TH - 2, ixb = 2 * (tile % a.tiles_x) * G::TW - 4;
+    const float *org = xb + (long)iy0 * a.W + ixb;
+#pragma unroll
+    for (int i = 0; i < R::NSP; ++i) {
+      const int q = wave + 4 * i;
+      if (q >= R::SQ) continue;
+      const bool ok = (unsigned)(iy0 + (g_rc[i] & 255)) < (unsigned)a.H && (unsigned)(ixb + (g_rc[i] >> 8)) < (unsigned)a.W;
+      glds16(ok ? static_cast<const void *>(org + g_rel[i]) : static_cast<const void *>(zero), s_raw + q * 64);
+    }
+  };
+  // my pixel groups to interleave: m = tid + 256 i -> (patch row, granule): the C bands' granules of 4 pixels become 4 C
+  // consecutive halfs of the patch row = 2 C dwords at patch column 4 g - 2 (patch column 0 = input column 2 tx0 - 2).  The
+  // first granule of a row holds two columns left of the patch (its first C dwords are skipped), the last one a single
+  // live column (ceil(C / 2) dwords: at odd C the extra half is a pad slot of the row tail).
+  constexpr int NRG = (G::PR * R::SG + 255) / 256;
+  int m_src[NRG], m_dst[NRG], m_lo[NRG], m_hi[NRG];
+#pragma unroll
+  for (int i = 0; i < NRG; ++i) {
+    const int m = tid + 256 * i;
+    const int prow = m / R::SG, g = m - prow * R::SG;
+    m_src[i] = m;                                                  // granule index inside band 0's rows
+    m_dst[i] = 2 * (prow * 8 * G::GR + (4 * g - 2) * C);           // byte offset inside the patch
+    m_lo[i] = m >= G::PR * R::SG ? 2 * C : (g == 0 ? C : 0);       // first and one-past-last dword written
+    m_hi[i] = g == R::SG - 1 ? (C + 1) / 2 : 2 * C;
+  }
+  auto repack = [&]() {
+    unsigned char *pb = reinterpret_cast<unsigned char *>(s_p);
+#pragma unroll
+    for (int i = 0; i < NRG; ++i) {
+      _Float16 hv[4 * C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float4 v = *reinterpret_cast<const float4 *>(s_raw + c * (G::PR * R::SG) + (m_src[i] < G::PR * R::SG ? m_src[i] : 0));
+        hv[0 * C + c] = (_Float16)v.x;
+        hv[1 * C + c] = (_Float16)v.y;
+        hv[2 * C + c] = (_Float16)v.z;
+        hv[3 * C + c] = (_Float16)v.w;
+      }
+#pragma unroll
+      for (int d = 0; d < 2 * C; ++d) {
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        const half2v pr = {hv[2 * d], hv[2 * d + 1]};
+        if (d >= m_lo[i] && d < m_hi[i]) *reinterpret_cast<unsigned *>(pb + m_dst[i] + 4 * d) = __builtin_bit_cast(unsigned, pr);
+      }
+    }
+  };
+
+  // resident operands, the first tile's raw rows; the patch's row tails (never rewritten) start as zeros
+#pragma unroll
+  for (int i = 0; i < G::NWP; ++i) {
+    const int q = wave + 4 * i;
+    if (q < 5 * MT) glds16(a.wp + q * 64 + lane, s_w + q * 64);
+  }
+  if (wave == 0) glds16((lane < 32 || !NORM) ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias);
+  if (NORM) {
+#pragma unroll
+    for (int i = 0; i < G::NGP; ++i) {
+      const int q = wave + 4 * i;
+      if (q < G::GAMMA_GRAN / 64) glds16(a.gamma + q * 64 + lane, s_gamma + q * 64);
+    }
+  }
+  dma_raw(0);
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int e = tid; e < G::PATCH_PAD; e += 256) s_p[e] = zero8;
+
+  f32x16 acc[MT][NT];
+  auto acc_init = [&]() {  // accumulators start at the bias: register q of tile mt is channel 32mt + (q&3) + 8(q>>2) + 4h
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(s_bias + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt][4 * g + 0] = bv.x;
+          acc[mt][nt][4 * g + 1] = bv.y;
+          acc[mt][nt][4 * g + 2] = bv.z;
+          acc[mt][nt][4 * g + 3] = bv.w;
+        }
+      }
+  };
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  repack();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (t_count > 1) dma_raw(1);  // tile 1's rows land under tile 0's MFMAs
+  acc_init();
+
+  const int lane_boff = 4 * r * C + 16 * h;
+  const int Cout16 = (a.Cout + 15) >> 4;
+  _Float16 *y_img = a.y_blk + (size_t)b * Cout16 * a.Ho * a.Wo * 16;
+  bool counted = false;  // the youngest NSTORE operations of this wave are the previous tile's stores
+  for (int t = 0; t < t_count; ++t) {
+    const unsigned char *pb = reinterpret_cast<const unsigned char *>(s_p) + lane_boff;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      half8 bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned *p = reinterpret_cast<const unsigned *>(pb + (2 * (wave * NT + nt) + ky) * G::GR * 16);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {p[0], p[1], p[2], p[3]};
+        bf[nt] = __builtin_bit_cast(half8, v);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const half8 af = s_w[(ky * MT + mt) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    // the raw rows of tile t+1 (requested before the previous epilogue, or above) have landed: everything older than this
+    // wave's last NSTORE operations is complete; after the barrier nobody reads the patch of tile t any more
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_count) repack();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < t_count) dma_raw(t + 2);  // the raw buffer is free now
+    asm volatile("" ::: "memory");        // the stores below stay behind that request
+    const int tile = t_first + t;
+    const int ty0 = (tile / a.tiles_x) * G::TH, tx0 = (tile % a.tiles_x) * G::TW;
+    long pix[NT];
+    bool all_live = a.Cout >= 32 * MT - 15;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = ty0 + wave * NT + nt, ox = tx0 + r;
+      pix[nt] = (oy < a.Ho && ox < a.Wo) ? (long)oy * a.Wo + ox : -1;
+      all_live = all_live && oy < a.Ho;
+    }
+    tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, y_img, (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    counted = all_live;
+    if (t + 1 < t_count) acc_init();
   }
 }
 
@@ -269,6 +456,30 @@ static int launch_first_epi(const FirstArgs &a, int epi, hipStream_t s) {
   return fail(LICOS_EINVAL, "conv5x5s2_first_f16: epilogue %d not supported (none, GDN, ReLU)", epi);
 }
 
+template <int C, int EPI>
+static int launch_first_raw(const FirstRawArgs &a, hipStream_t s) {
+  using G = FirstGeom<C>;
+  using R = FirstRawGeom<C>;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int run = tiles >= 8 ? 8 : tiles;
+  const size_t lds = (size_t)16 * (R::S_PAD + G::PATCH_PAD + G::W_GRAN + 16 * G::MT + (EPI == EPI_GDN ? G::GAMMA_GRAN : 0));
+  auto kern = conv5x5s2_first_raw_kernel<C, EPI>;
+  LICOS_ENSURE_LDS(kern, lds);
+  const long blocks = (long)cdiv(tiles, run) * a.B;
+  LICOS_REQUIRE(blocks < (1L << 31), "conv5x5s2_first_nchw_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, a, run);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+template <int C>
+static int launch_first_raw_epi(const FirstRawArgs &a, int epi, hipStream_t s) {
+  if (epi == EPI_GDN) return launch_first_raw<C, EPI_GDN>(a, s);
+  if (epi == EPI_NONE) return launch_first_raw<C, EPI_NONE>(a, s);
+  if (epi == EPI_RELU) return launch_first_raw<C, EPI_RELU>(a, s);
+  return fail(LICOS_EINVAL, "conv5x5s2_first_nchw_f16: epilogue %d not supported (none, GDN, ReLU)", epi);
+}
+
 }  // namespace licos
 
 using namespace licos;
@@ -301,12 +512,13 @@ int licos_nchw_f32_to_hwc_pad_f16(const float *x_nchw, void *out, int B, int C, 
 
 size_t licos_packed_conv_w_first_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cin > 3 || Cout <= 0 || Cout > 128) return 0;
-  return (size_t)5 * 4 * 64 * 16;
+  return (size_t)5 * 4 * 64 * 16 + 64;  // + a granule of zeros (and padding): the in-place form's source for padding
 }
 
 int licos_pack_conv_w_first_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
   LICOS_REQUIRE(w && packed && Cin > 0 && Cin <= 3 && Cout > 0 && Cout <= 128, "pack_conv_w_first_f16: needs 1..3 input and <= 128 output channels");
   const long total = (long)5 * 4 * 64 * 8;
+  LICOS_HIP_CHECK(hipMemsetAsync(static_cast<unsigned char *>(packed) + total * 2, 0, 64, as_stream(stream)));
   hipLaunchKernelGGL(pack_conv_w_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, Cin, Cout, 4,
                      reinterpret_cast<_Float16 *>(packed), total);
   LICOS_LAUNCH_CHECK();
@@ -337,8 +549,6 @@ int licos_conv5x5s2_first_f16(const void *x_hwc_pad, const void *w_packed_first,
   a.tiles_x = cdiv(a.Wo, FirstGeom<1>::TW);
   a.tiles_y = cdiv(a.Ho, FirstGeom<1>::TH);
   a.rsg = first_row_halfs(W, Cin);
-  static const int skew = [] { const char *e = getenv("LICOS_FIRST_SKEW"); return e ? atoi(e) : 8; }();
-  a.skew = skew;
   LICOS_REQUIRE((long)a.Ho * a.Wo * ((Cout + 15) / 16) * 32 < (1L << 32), "conv5x5s2_first_f16: an image's output must stay below 4 GB (32-bit store offsets)");
   LICOS_REQUIRE((long)(H + 4 + 2 * FirstGeom<1>::TH + 4) * a.rsg * 2 < (1L << 31), "conv5x5s2_first_f16: image too large");
   hipStream_t s = as_stream(stream);
@@ -346,6 +556,41 @@ int licos_conv5x5s2_first_f16(const void *x_hwc_pad, const void *w_packed_first,
     case 1: return launch_first_epi<1>(a, epilogue, s);
     case 2: return launch_first_epi<2>(a, epilogue, s);
     default: return launch_first_epi<3>(a, epilogue, s);
+  }
+}
+
+int licos_conv5x5s2_first_nchw_f16(const float *x_nchw, const void *w_packed_first, const float *bias, const void *gdn_packed, int epilogue,
+                                   void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream) {
+  LICOS_REQUIRE(x_nchw && w_packed_first && bias && y_blk16, "conv5x5s2_first_nchw_f16: null buffer");
+  LICOS_REQUIRE(B > 0 && Cin > 0 && Cin <= 3 && H > 0 && W > 0 && Cout > 0 && Cout <= 128,
+                "conv5x5s2_first_nchw_f16: needs 1..3 input and <= 128 output channels");
+  LICOS_REQUIRE(W % 4 == 0, "conv5x5s2_first_nchw_f16: the width must be a multiple of 4 (16-byte granules of the fp32 rows); use "
+                            "licos_nchw_f32_to_hwc_pad_f16 + licos_conv5x5s2_first_f16 otherwise");
+  LICOS_REQUIRE(epilogue != EPI_GDN || gdn_packed, "conv5x5s2_first_nchw_f16: the GDN epilogue needs packed gamma/beta");
+  LICOS_REQUIRE(((uintptr_t)x_nchw & 15) == 0 && ((uintptr_t)w_packed_first & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)y_blk16 & 15) == 0,
+                "conv5x5s2_first_nchw_f16: buffers must be 16-byte aligned");
+  FirstRawArgs a{};
+  a.x = x_nchw;
+  a.wp = static_cast<const half8 *>(w_packed_first);
+  a.bias = bias;
+  a.gamma = static_cast<const bf16x8 *>(gdn_packed);
+  a.beta = gdn_packed ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(gdn_packed) + (size_t)4 * 4 * 2 * 1024) : bias;
+  a.y_blk = static_cast<_Float16 *>(y_blk16);
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Ho = (H - 1) / 2 + 1;
+  a.Wo = (W - 1) / 2 + 1;
+  a.Cout = Cout;
+  a.tiles_x = cdiv(a.Wo, FirstGeom<1>::TW);
+  a.tiles_y = cdiv(a.Ho, FirstGeom<1>::TH);
+  LICOS_REQUIRE((long)a.Ho * a.Wo * ((Cout + 15) / 16) * 32 < (1L << 32), "conv5x5s2_first_nchw_f16: an image's output must stay below 4 GB (32-bit store offsets)");
+  LICOS_REQUIRE((long)Cin * H * W < (1L << 30), "conv5x5s2_first_nchw_f16: image too large");
+  hipStream_t s = as_stream(stream);
+  switch (Cin) {
+    case 1: return launch_first_raw_epi<1>(a, epilogue, s);
+    case 2: return launch_first_raw_epi<2>(a, epilogue, s);
+    default: return launch_first_raw_epi<3>(a, epilogue, s);
   }
 }
 

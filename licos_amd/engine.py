@@ -44,6 +44,7 @@ def _pver(p):
 
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
 FIRST_ROWS = os.environ.get("LICOS_FIRST", "1") != "0"  # kernel-row first stage (1..3 bands) instead of the space-to-depth 3x3 form
+FIRST_RAW = os.environ.get("LICOS_FIRST_RAW", "1") != "0"  # ... reading the NCHW fp32 image in place (no layout pass) when W % 4 == 0
 ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
 
 
@@ -134,9 +135,10 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
                       and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in and x.shape[1] <= 3
                       and st[0][0].out_channels <= 128 and len(st) > 1 and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse)
                       and min(h0, w0) >= 16)
+        first_raw = first_rows and FIRST_RAW and w0 % 4 == 0
         if first_rows:
             s2d_first = False
-            cur = ops.nchw_f32_to_hwc_pad_f16(x.contiguous())
+            cur = x.contiguous() if first_raw else ops.nchw_f32_to_hwc_pad_f16(x.contiguous())
         else:
             cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
     else:
@@ -183,7 +185,10 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         norm = gp is not None
         if first_rows and idx == 0:
             key = ("conv", m.in_channels, m.out_channels, h0, w0, x.shape[0], norm)
-            cur = _timed(key, lambda: ops.conv5x5s2_first_f16(cur, wp, bp, gp, epi, x.shape[0], m.in_channels, m.out_channels, h0, w0))
+            if first_raw:
+                cur = _timed(key, lambda: ops.conv5x5s2_first_nchw_f16(cur, wp, bp, gp, epi, m.out_channels))
+            else:
+                cur = _timed(key, lambda: ops.conv5x5s2_first_f16(cur, wp, bp, gp, epi, x.shape[0], m.in_channels, m.out_channels, h0, w0))
             continue
         if s2d_first and idx == 0:
             key = ("conv", m.in_channels, m.out_channels, h0, w0, cur.shape[0], norm)

@@ -579,6 +579,14 @@ def test_first_stage_kernel_rows_equals_conv(cin, cout, h, w, epi):
     # a tile's bits do not depend on the batch it is in
     one = ops.conv5x5s2_first_f16(ops.nchw_f32_to_hwc_pad_f16(x[2:3].to(DEV)), wp, bp, gp, e, 1, cin, cout, h, w)
     assert torch.equal(one, out[2:3])
+    if w % 4 == 0:  # the in-place form (fp32 rows by LDS-DMA, interleaved LDS to LDS): the same bits, no layout pass
+        xd = x.to(DEV)
+        raw = ops.conv5x5s2_first_nchw_f16(xd, wp, bp, gp, e, cout)
+        assert torch.equal(raw, out)
+        assert torch.equal(ops.conv5x5s2_first_nchw_f16(xd[1:2].contiguous(), wp, bp, gp, e, cout), out[1:2])
+    else:
+        with pytest.raises(ValueError):
+            ops.conv5x5s2_first_nchw_f16(x.to(DEV), wp, bp, gp, e, cout)
 
 
 def test_first_stage_kernel_rows_rejects_unsupported_shapes():

@@ -16,6 +16,10 @@ if form == "rows":
     wp = ops.pack_conv_w_first_f16(w)
     prep = lambda: ops.nchw_f32_to_hwc_pad_f16(x)
     conv = lambda xi: ops.conv5x5s2_first_f16(xi, wp, bp, gp, ops.EPI_GDN, B, cin, 128, 256, 256)
+elif form == "raw":
+    wp = ops.pack_conv_w_first_f16(w)
+    prep = lambda: x
+    conv = lambda xi: ops.conv5x5s2_first_nchw_f16(xi, wp, bp, gp, ops.EPI_GDN, 128)
 else:
     wp = ops.pack_conv_w_s2d_f16(w)
     prep = lambda: ops.nchw_f32_to_s2d_blk16(x)

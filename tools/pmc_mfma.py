@@ -16,7 +16,7 @@ def main():
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if not any(k in name for k in ("mfma", "fewch", "conv3x3s1", "scatter", "rows_kernel", "first_kernel", "hwc_pad", "rans_")):
+            if not any(k in name for k in ("mfma", "fewch", "conv3x3s1", "scatter", "rows_kernel", "first_", "hwc_pad", "rans_")):
                 continue
             key = (name, int(r["Grid_Size"]))
             per[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -1,0 +1,34 @@
+"""Dev tool: is the big transposed-conv stage (128 -> 128 + IGDN at 64^2 -> 128^2) bounded by its instruction stream or by
+the chip's power limit?  The same kernel, the same launch, the same instruction stream on (a) random operands, (b) an
+all-zero input with random weights, (c) all-zero input and weights: matrix-core power follows operand toggling, so on a
+power-limited launch (b) / (c) run at a higher clock and finish sooner; a stream-bound kernel does not care.
+  python tools/power_probe.py [tiles=4096] [reps=12]"""
+import sys, os, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import licos_amd
+from licos_amd import ops, engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(1)
+gp = engine._packed_gdn(licos_amd.GDN(128, inverse=True).to(dev))
+bp = ops.pad_bias(torch.zeros(128, device=dev), 128, dev)
+fl = 2.0 * 128 * 128 * (25 / 4.0 * 128 * 128 + 128 * 128) * B
+for name, xs, ws in (("random x, random w", 1.0, 0.03), ("zero x, random w", 0.0, 0.03), ("zero x, zero w", 0.0, 0.0)):
+    x = (torch.randn(B, 8, 64, 64, 16, device=dev, generator=g) * xs).half()
+    w = torch.randn(128, 128, 5, 5, device=dev, generator=g) * ws
+    wp = ops.pack_conv_w_f16(w, transposed=True)
+    ts = []
+    for it in range(reps + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = ops.deconv5x5s2_f16(x, wp, bp, gp, ops.EPI_IGDN | ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT, 128, 128)
+        e1.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            ts.append(e0.elapsed_time(e1))
+        del y
+    ts.sort()
+    med = ts[len(ts) // 2]
+    print("%-20s median %.3f ms  min %.3f  max %.3f  -> %.0f TFLOP/s conv + IGDN MACs (%.3f of 2.5 PF)" % (name, med, ts[0], ts[-1], fl / med / 1e9, fl / med / 1e9 / 2500))
+    del x, w, wp

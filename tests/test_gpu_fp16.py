@@ -537,7 +537,8 @@ def test_first_stage_space_to_depth_equals_conv(cin, h, w):
 
 @pytest.mark.parametrize("cin,cout,h,w,epi", [(3, 128, 64, 64, "none"), (1, 128, 32, 48, "none"), (3, 128, 256, 256, "gdn"),
                                                (2, 128, 18, 70, "relu"), (3, 96, 16, 16, "none"), (3, 128, 50, 130, "gdn"),
-                                               (1, 128, 256, 256, "gdn"), (3, 128, 37, 65, "none")])
+                                               (1, 128, 256, 256, "gdn"), (3, 128, 37, 65, "none"), (3, 128, 37, 64, "gdn"),
+                                               (1, 128, 19, 100, "relu"), (2, 128, 16, 260, "none")])
 def test_first_stage_kernel_rows_equals_conv(cin, cout, h, w, epi):
     """First analysis stage with K steps = kernel rows over the interleaved zero-bordered fp16 image (csrc/mfma_first.hip,
     two 4-wave workgroups per CU): same operands as torch-CPU conv2d; ragged tiles, odd sizes, 1..3 bands, every epilogue;

@@ -366,6 +366,51 @@ def test_model_fp16_matches_oracle_rates(cin, kind):
     assert rel_err(dec["x_hat"], out["x_hat"].clamp(0, 1)) < 1e-6
 
 
+@pytest.mark.parametrize("cin", [3, 1])
+def test_default_fp16_path_runs_the_band_sized_end_stage_kernels(cin, monkeypatch):
+    """The fp16 path of an RGB / single-band model goes through the in-place first stage (csrc/mfma_first.hip) and the
+    row-walking last stage (csrc/mfma_rows.hip) - a silent fall-back to the older forms would keep every parity test green
+    and lose 8 % of the headline - and agrees with those older forms (same operands, other fp32 summation orders)."""
+    from licos_amd import synthetic
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 3).to(DEV).eval().set_precision("fp16")
+    with torch.no_grad():
+        synthetic.make_trained_like(net, seed=7)
+    x = om.synthetic_tiles(5, cin, 256, seed=11).to(DEV)
+    calls = {"first": 0, "rows": 0}
+    real_first, real_rows = ops.conv5x5s2_first_nchw_f16, ops.deconv5x5s2_rows_f16
+
+    def first(*a, **k):
+        calls["first"] += 1
+        return real_first(*a, **k)
+
+    def rows(*a, **k):
+        calls["rows"] += 1
+        return real_rows(*a, **k)
+
+    monkeypatch.setattr(ops, "conv5x5s2_first_nchw_f16", first)
+    monkeypatch.setattr(ops, "deconv5x5s2_rows_f16", rows)
+    with torch.no_grad():
+        y = net.g_a(x)
+        xh = net.g_s(y)
+    assert calls == {"first": 1, "rows": 1}
+    monkeypatch.setattr(engine, "FIRST_ROWS", False)
+    monkeypatch.setattr(engine, "ROWS_LAST", False)
+    with torch.no_grad():
+        y_old = net.g_a(x)
+        xh_old = net.g_s(y)
+    assert calls == {"first": 1, "rows": 1}  # the switches really select the older kernels
+    assert rel_err(y, y_old) < 5e-3 and rel_err(xh, xh_old) < 1e-4
+    # width not a multiple of 4: the layout-pass form of the same first stage
+    monkeypatch.setattr(engine, "FIRST_ROWS", True)
+    x2 = x[:2, :, :, :254].contiguous()
+    with torch.no_grad():
+        y2 = net.g_a(x2)
+    assert calls["first"] == 1 and tuple(y2.shape[-2:]) == (16, 16)
+    monkeypatch.setattr(engine, "FIRST_ROWS", False)
+    with torch.no_grad():
+        assert rel_err(y2, net.g_a(x2)) < 5e-3
+
+
 def test_bench_scale_batch_invariants():
     """The bench workload (BASELINE configs[1]: q=3, 3-channel 256x256 tiles, fp16) at a batch far beyond what the
     oracle can follow, checked through size-independent properties: decode(encode(x)) equals forward()'s

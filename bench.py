@@ -555,8 +555,9 @@ def main():
                                              "(SURVEY.md 8(d): a tile's work is conv + GDN MACs x 2)",
                     "frac_conv_only": round(fl_conv / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                     "algorithmic_bytes_per_launch": 2 * (key[1] * key[3] * key[4] + key[2] * (key[3] * key[4] * (4 if key[0] == "deconv" else 0.25))) * LB,
-                    "power_note": "operand-data dependent (DVFS): the g_s[4] launch measured 14.60 ms on random operands and 10.08 ms on "
-                                  "all-zero ones, same instruction stream and traffic - profiles/r03_power_probe.log (tools/power_probe.py)"}
+                    "power_note": "operand-data dependent (DVFS): the g_s[4] / g_a[2] launches measured 14.13 / 12.23 ms on random operands and "
+                                  "10.01 / 8.26 ms on all-zero ones, same instruction stream and traffic - profiles/r03_power_probe.log "
+                                  "(tools/power_probe.py)"}
 
         # `roofline` = the DOMINANT kernel of the step (largest total time among the MFMA stages, full-size launches);
         # the north-star target kernel g_a[2] rides along as `roofline_g_a2`

@@ -14,21 +14,31 @@ g = torch.Generator(device=dev).manual_seed(1)
 gp = engine._packed_gdn(licos_amd.GDN(128, inverse=True).to(dev))
 bp = ops.pad_bias(torch.zeros(128, device=dev), 128, dev)
 fl = 2.0 * 128 * 128 * (25 / 4.0 * 128 * 128 + 128 * 128) * B
-for name, xs, ws in (("random x, random w", 1.0, 0.03), ("zero x, random w", 0.0, 0.03), ("zero x, zero w", 0.0, 0.0)):
-    x = (torch.randn(B, 8, 64, 64, 16, device=dev, generator=g) * xs).half()
-    w = torch.randn(128, 128, 5, 5, device=dev, generator=g) * ws
-    wp = ops.pack_conv_w_f16(w, transposed=True)
-    ts = []
-    for it in range(reps + 3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = ops.deconv5x5s2_f16(x, wp, bp, gp, ops.EPI_IGDN | ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT, 128, 128)
-        e1.record()
-        torch.cuda.synchronize()
-        if it >= 3:
-            ts.append(e0.elapsed_time(e1))
-        del y
-    ts.sort()
-    med = ts[len(ts) // 2]
-    print("%-20s median %.3f ms  min %.3f  max %.3f  -> %.0f TFLOP/s conv + IGDN MACs (%.3f of 2.5 PF)" % (name, med, ts[0], ts[-1], fl / med / 1e9, fl / med / 1e9 / 2500))
-    del x, w, wp
+gpf = engine._packed_gdn(licos_amd.GDN(128).to(dev))
+fl_a = 2.0 * 64 * 64 * (25.0 * 128 * 128 + 128 * 128) * B
+for stage in ("g_s[4] deconv + IGDN 64^2 -> 128^2", "g_a[2] conv + GDN 128^2 -> 64^2"):
+    dec = stage.startswith("g_s")
+    print(stage)
+    for name, xs, ws in (("random x, random w", 1.0, 0.03), ("zero x, random w", 0.0, 0.03), ("zero x, zero w", 0.0, 0.0)):
+        hw = 64 if dec else 128
+        x = (torch.randn(B, 8, hw, hw, 16, device=dev, generator=g) * xs).half()
+        w = torch.randn(128, 128, 5, 5, device=dev, generator=g) * ws
+        wp = ops.pack_conv_w_f16(w, transposed=dec)
+        ts = []
+        for it in range(reps + 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if dec:
+                y = ops.deconv5x5s2_f16(x, wp, bp, gp, ops.EPI_IGDN | ops.EPI_IN_XSPLIT | ops.EPI_OUT_XSPLIT, 128, 128)
+            else:
+                y = ops.conv5x5s2_f16(x, wp, bp, gpf, ops.EPI_GDN, 128, 128)
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                ts.append(e0.elapsed_time(e1))
+            del y
+        ts.sort()
+        med = ts[len(ts) // 2]
+        f = fl if dec else fl_a
+        print("  %-20s median %.3f ms  min %.3f  max %.3f  -> %.0f TFLOP/s conv + norm MACs (%.3f of 2.5 PF)" % (name, med, ts[0], ts[-1], f / med / 1e9, f / med / 1e9 / 2500))
+        del x, w, wp

@@ -167,6 +167,16 @@ def stage_entry(key, ms, launches):
             nbytes = (cin * h * w * 2 + cout * (2 * h) * (2 * w) * 4) * b
         ent.update({"bound": "hbm", "GBps": round(nbytes / ms / 1e6, 1), "frac_hbm": round(nbytes / ms / 1e9 / PEAK_HBM_TBPS, 4),
                     "algorithmic_bytes_per_launch": nbytes})
+        # HBM-side traffic from the PMC passes of the 3-band 256^2 launches (profiles/README.md), scaled to this launch size
+        tfile = None
+        if few_in and (cin, h, w) == (3, 256, 256):
+            tfile = "r03_pmc_traffic_first.json"
+        elif few_out and (cout, h, w) == (3, 128, 128):
+            tfile = "r03_pmc_traffic_rows.json"
+        if tfile and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
+            ent["traffic"] = tj["hbm_bytes_per_launch"] * b / tj["tiles_per_launch"]
+            ent["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tfile
     return ent
 
 

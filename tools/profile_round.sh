@@ -24,5 +24,7 @@ cd $root
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_traffic.py $f $w "deconv5x5s2_mfma8_kernel" 4096 5242880 $out/pmc_traffic_deconv_s4.json
 python tools/pmc_traffic.py $f $w "conv5x5s2_mfma8_kernel" 4096 5242880 $out/pmc_traffic_conv_a3.json
+python tools/pmc_traffic.py $f $w "conv5x5s2_first_raw_kernel" 4096 4980736 $out/pmc_traffic_first.json
+python tools/pmc_traffic.py $f $w "deconv5x5s2_rows_kernel" 4096 4980736 $out/pmc_traffic_rows.json
 python tools/pmc_mfma.py $(find $out/pmc_mfma -name "*counter_collection.csv" | head -1) $out/pmc_mfma_busy.json
 rm -rf $out/stats $out/hyper $out/train $out/fp32 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma

@@ -337,3 +337,34 @@ def test_fp32_path_shape_queries_and_argument_checks():
                  lambda: lib.licos_pack_gdn_f32split(None, None, 0.0, 0.0, 0.0, 128, None, None)):
         assert call() == -1  # LICOS_EINVAL
         assert lib.licos_last_error()
+
+
+def test_band_sized_end_stage_queries_and_argument_checks():
+    """Host-side answers of the first / last stage entry points for 1..3 bands (csrc/mfma_first.hip, mfma_rows.hip): operand
+    sizes, and bad arguments as LICOS_EINVAL with a message instead of a launch (no GPU needed)."""
+    from licos_amd import _lib
+    lib = _lib.load()
+    # last stage: 3 row shifts x Cin / 16 A fragments of 1 KB; 1..3 bands only
+    assert lib.licos_packed_deconv_w_rows_bytes(128, 3) == 3 * 8 * 1024 and lib.licos_packed_deconv_w_rows_bytes(192, 1) == 3 * 12 * 1024
+    assert lib.licos_packed_deconv_w_rows_bytes(128, 4) == 0 and lib.licos_packed_deconv_w_rows_bytes(0, 3) == 0
+    # first stage: 5 kernel rows x 4 channel tiles of 1 KB + the zero granule; 1..3 bands into <= 128 channels
+    assert lib.licos_packed_conv_w_first_bytes(3, 128) == 5 * 4 * 1024 + 64
+    assert lib.licos_packed_conv_w_first_bytes(4, 128) == 0 and lib.licos_packed_conv_w_first_bytes(3, 192) == 0
+    # interleaved zero-bordered image: (H + 4) rows of round_up((W + 4) C + 8, 8) halfs per image, plus edge-tile slack
+    rs = ((256 + 4) * 3 + 8 + 7) // 8 * 8
+    n = lib.licos_hwc_pad_f16_bytes(2, 3, 256, 256)
+    assert n >= 2 * 260 * rs * 2 and n <= (2 * 260 + 32) * rs * 2 + 4096 and lib.licos_hwc_pad_f16_bytes(1, 4, 256, 256) == 0
+    one = ctypes.c_void_p(16)  # a non-null, 16-byte aligned stand-in: the checks below fail before any dereference
+    for call in (lambda: lib.licos_deconv5x5s2_rows_f16(None, None, None, None, 0, 1, 128, 8, 8, 3, None),
+                 lambda: lib.licos_deconv5x5s2_rows_f16(one, one, one, one, 0, 1, 128, 8, 8, 4, None),      # 4 bands
+                 lambda: lib.licos_deconv5x5s2_rows_f16(one, one, one, one, 2, 1, 128, 8, 7, 3, None),      # x-split needs an even width
+                 lambda: lib.licos_deconv5x5s2_rows_f16(one, one, one, one, 0, 1, 64, 8, 8, 3, None),       # 64 input channels
+                 lambda: lib.licos_conv5x5s2_first_nchw_f16(None, None, None, None, 0, None, 1, 3, 64, 64, 128, None),
+                 lambda: lib.licos_conv5x5s2_first_nchw_f16(one, one, one, None, 0, one, 1, 3, 64, 66, 128, None),  # W % 4
+                 lambda: lib.licos_conv5x5s2_first_nchw_f16(one, one, one, None, 1, one, 1, 3, 64, 64, 128, None),  # GDN without gamma
+                 lambda: lib.licos_conv5x5s2_first_f16(one, one, one, None, 0, one, 1, 4, 64, 64, 128, None),       # 4 bands
+                 lambda: lib.licos_pack_deconv_w_rows_f16(one, 128, 4, one, None),
+                 lambda: lib.licos_pack_conv_w_first_f16(one, 3, 192, one, None),
+                 lambda: lib.licos_nchw_f32_to_hwc_pad_f16(one, one, 1, 4, 16, 16, None)):
+        assert call() == -1  # LICOS_EINVAL
+        assert lib.licos_last_error()

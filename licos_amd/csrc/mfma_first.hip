@@ -464,7 +464,14 @@ static int launch_first_raw(const FirstRawArgs &a, hipStream_t s) {
   using G = FirstGeom<C>;
   using R = FirstRawGeom<C>;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int run = tiles >= 8 ? 8 : tiles;
+  // tiles per workgroup: the resident operands (53 KB) and the first tile's exposed request are paid once per run - 16 for
+  // large calls (4.74 against 4.80 ms per 4096 tiles at 8), fewer while the call has fewer than ~1024 workgroups to fill
+  // the chip's 512 slots with (a single tile: 64 workgroups of one tile each instead of 8 of eight)
+  static const int run_env = [] { const char *e = getenv("LICOS_FIRST_RUN"); return e ? atoi(e) : 0; }();
+  long want = (long)a.B * tiles / 1024;
+  want = want < 1 ? 1 : (want > 16 ? 16 : want);
+  const int run_max = run_env > 0 ? run_env : (int)want;
+  const int run = tiles >= run_max ? run_max : tiles;
   const size_t lds = (size_t)16 * (R::S_PAD + G::PATCH_PAD + G::W_GRAN + 16 * G::MT + (EPI == EPI_GDN ? G::GAMMA_GRAN : 0));
   auto kern = conv5x5s2_first_raw_kernel<C, EPI>;
   LICOS_ENSURE_LDS(kern, lds);

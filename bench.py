@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16 MFMA (MI355X_MICROARCH.md chip table)
 XGMI_PEAK_GBPS = 7 * 153.0         # per GPU: 7 links x ~153 GB/s
+NATIVE_WATCHDOG_S = float(os.environ.get("LICOS_NATIVE_WATCHDOG_S", "120"))  # the native-RCCL leg's time limit
 
 
 def parse_args():
@@ -57,8 +58,9 @@ def parse_args():
     return ap.parse_args()
 
 
-def spawn_workers(args, limit_s=3000.0):
+def spawn_workers(args, limit_s=3000.0, cmd=None):
     """--gpus N without a launcher: N fresh worker processes, started BEFORE anything here touches the GPU.
+    (`cmd`: the worker command line, this script by default - the CPU tests pass a stand-in.)
     The parent watches ALL of them: the first rank to exit non-zero (RCCL initialisation, out of memory, a GPU fault)
     ends the others - left alone they would sit in their next collective until its timeout - and becomes the exit
     status; so does the wall-clock limit.  The workers form their own process group, which is killed as a whole when the
@@ -76,10 +78,11 @@ def spawn_workers(args, limit_s=3000.0):
     pgid = None
 
     def kill_group(*_):
+        # (pgid is cleared once every worker has been reaped: a process-group id may be reused by strangers afterwards)
         if pgid is not None:
             try:
                 os.killpg(pgid, signal.SIGKILL)
-            except ProcessLookupError:
+            except OSError:  # ProcessLookupError: already gone; PermissionError: no longer ours
                 pass
 
     def on_signal(signum, _frame):
@@ -95,7 +98,7 @@ def spawn_workers(args, limit_s=3000.0):
         log = tempfile.TemporaryFile()  # every rank's stderr is kept: the failing rank's tail is what explains an exit
         logs.append(log)
         # rank 0 leads a new process group (same session), the others join it
-        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        p = subprocess.Popen(cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
                              stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=log,
                              preexec_fn=(lambda g=(pgid or 0): os.setpgid(0, g)))
         if pgid is None:
@@ -125,11 +128,18 @@ def spawn_workers(args, limit_s=3000.0):
         while time.monotonic() < deadline and any(p.poll() is None for p in procs):
             time.sleep(0.1)
         kill_group()
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
         for r, log in enumerate(logs):
             log.seek(0)
             tail = log.read().decode("utf-8", "replace")[-1500:]
             if tail.strip():
                 sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, tail))
+    if all(p.poll() is not None for p in procs):
+        pgid = None  # every worker reaped: nothing of ours is left under that id
     out0.seek(0)
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
@@ -239,8 +249,10 @@ def cpu_baseline(sd, cin, budget_s=22.0):
     return best["tiles_s"], time.perf_counter() - t_start, best["threads"], grid
 
 
-def timed_codec(net, x, reps, plain=False, split=False):
-    """Median wall time (ms) of compress(x) + decompress(...) over `reps` runs, device-synchronised."""
+def timed_codec(net, x, reps, plain=False, split=False, after_warmup=None):
+    """Median wall time (ms) of compress(x) + decompress(...) over `reps` runs, device-synchronised.  The first run is an
+    untimed warm-up (it pays this size's allocations); `after_warmup()` runs right behind it - where per-stage event
+    collection is armed, so that no cold hipMalloc lands between a stage's two events."""
     import torch
     enc_t, dec_t = [], []
     with torch.no_grad():
@@ -258,6 +270,8 @@ def timed_codec(net, x, reps, plain=False, split=False):
             if i:
                 enc_t.append(1e3 * (t1 - t0))
                 dec_t.append(1e3 * (t2 - t1b))
+            elif after_warmup is not None:
+                after_warmup()
     enc_t.sort()
     dec_t.sort()
     e, dd = enc_t[len(enc_t) // 2], dec_t[len(dec_t) // 2]
@@ -335,8 +349,8 @@ def extras(args, net, x, dev):
     torch.cuda.empty_cache()
     try:
         configs["hyperprior_13x512"] = hyperprior_grid(args, dev)
-    except torch.OutOfMemoryError as e:  # reported, never fatal for the headline
-        configs["hyperprior_13x512"] = {"error": str(e)[:200]}
+    except (torch.OutOfMemoryError, ValueError, RuntimeError) as e:  # reported, never fatal for the headline
+        configs["hyperprior_13x512"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     out["configs"] = configs
     torch.cuda.empty_cache()
     out["train_step"] = train_step_ms(dev, steps=10)[0]
@@ -364,12 +378,17 @@ def hyperprior_grid(args, dev):
     out = {"weights": weights, "gflop_per_tile": 54.76}
     free = torch.cuda.mem_get_info(dev)[0]
     sizes = [b for b in (2048, 4096, 256) if b * 2 * 13 * 512 * 512 * 4 * 1.6 < free]
+    if not sizes:
+        return dict(out, error="not enough free device memory for 256 tiles of 13x512x512 (%.1f GiB free)" % (free / 2 ** 30))
     x = synthetic.tiles(max(sizes), 13, 512, seed=300, kind="s2-merged", device=dev)
+
+    def arm():
+        engine.stage_events, codec.coder_events = {}, {}
+
     for b in sizes:
         xb = x[:b]
-        if b == 2048 or (2048 not in sizes and b == sizes[0]):
-            engine.stage_events, codec.coder_events = {}, {}
-        res, c, d = timed_codec(net, xb, 3, split=True)
+        detailed = b == 2048 or (2048 not in sizes and b == sizes[0])
+        res, c, d = timed_codec(net, xb, 3, split=True, after_warmup=arm if detailed else None)
         res["gflops_frac_of_peak"] = round(54.76e9 * res["tiles_s"] / 1e12 / PEAK_F16_TFLOPS, 4)
         if engine.stage_events is not None:
             ev, cev = engine.stage_events, codec.coder_events
@@ -378,6 +397,10 @@ def hyperprior_grid(args, dev):
             res["bpp_actual"] = round(nbytes * 8.0 / (b * 512 * 512), 4)
             res["psnr_db"] = round(licos_amd.metrics.compute_psnr(d["x_hat"], xb), 3)
             stages, dom = {}, None
+            tj = None
+            tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic_hyper_deconv.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
             for key, evs in ev.items():
                 ms_all = [e0.elapsed_time(e1) for e0, e1 in evs]
                 ms = sum(ms_all) / len(ms_all)
@@ -391,7 +414,9 @@ def hyperprior_grid(args, dev):
                 res["roofline"] = {"kernel": "%s_%d_%d_%dx%d" % key[:5], "bound": "mfma", "achieved": round(fl / ms / 1e9, 2),
                                    "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
                                    "frac_conv_only": round(stage_flops(*key[:5]) * key[5] / ms / 1e9 / PEAK_F16_TFLOPS, 4),
-                                   "avg_launch_ms": round(ms, 4), "tiles_per_launch": key[5], "traffic": None}
+                                   "avg_launch_ms": round(ms, 4), "tiles_per_launch": key[5], "launches": len(ev[key]),
+                                   "traffic": (tj["hbm_bytes_per_launch"] * key[5] / tj["tiles_per_launch"]) if tj else None,
+                                   "traffic_source": "profiles/r04_pmc_traffic_hyper_deconv.json" if tj else None}
             nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
             coders = {}
             for key, evs in cev.items():
@@ -650,57 +675,86 @@ def main():
                              "cell (%d threads)"
                              % (dt, os.cpu_count() or 0, threads)}
 
-    def emit():
-        if rank != 0:
-            return
-        value = world * B * args.steps / elapsed
-        line = {
-            "metric": "256x256 tiles/s encode+decode (bpp+PSNR matched)" if args.size == 256 else
-            "%dx%d tiles/s encode+decode" % (args.size, args.size), "value": round(value, 1), "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": "%s q=%d, %d-ch %dx%d tiles, compress()+decompress() through the "
-                                   "module API, %d tiles per GPU per step" % (args.model.replace("-", "_"), args.quality,
-                                                                              args.channels, args.size, args.size, B),
-                       "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": weights},
-            "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
-            "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
-            "stages": stages,
-        }
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
 
-        print(json.dumps(line), file=json_out)
-        json_out.flush()
+    def emit():
+        """Prints the line ONCE (the watchdog thread and the main thread may both get here)."""
+        with emit_lock:
+            if emitted[0] or rank != 0:
+                emitted[0] = True
+                return
+            emitted[0] = True
+            value = world * B * args.steps / elapsed
+            line = {
+                "metric": "256x256 tiles/s encode+decode (bpp+PSNR matched)" if args.size == 256 else
+                "%dx%d tiles/s encode+decode" % (args.size, args.size), "value": round(value, 1), "unit": "tiles/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+                "config": {"workload": "%s q=%d, %d-ch %dx%d tiles, compress()+decompress() through the "
+                                       "module API, %d tiles per GPU per step" % (args.model.replace("-", "_"), args.quality,
+                                                                                  args.channels, args.size, args.size, B),
+                           "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": weights},
+                "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
+                "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
+                "stages": stages,
+            }
+            # the driver keeps the TAIL of the line: the small per-batch table rides at the very end
+            if grid and "batches" in grid:
+                line["batches"] = grid["batches"]
+            print(json.dumps(line), file=json_out)
+            json_out.flush()
 
     # The library's own RCCL communicator has never run with more than one rank before the driver's multi-GPU run (one
     # GPU per builder box).  It is timed LAST, under a watchdog: if it has not finished in 120 s - a rank stuck in
-    # ncclCommInitRank, say - every rank reports what it has (rank 0 prints the line without `native_rccl`) and leaves.
+    # ncclCommInitRank, say - that is a GPU hang: every rank says on stderr which call it was in, rank 0 prints the line
+    # it has (without `native_rccl` figures) and the process exits NON-ZERO (3), so the spawner / the driver stops the
+    # peers and records the run as failed.
     if world > 1 and args.backend == "nccl" and fed is not None:
-        import threading
+        native_stage = ["federation.NativeComm() (licos_comm_unique_id / licos_comm_init -> ncclCommInitRank)"]
+        native_done = [False]
 
         def bail():
-            fed["native_rccl"] = {"error": "timed out after 120 s (watchdog); the torch.distributed figures above stand"}
+            with emit_lock:
+                if native_done[0]:
+                    return  # the main thread finished while the timer fired: nothing hung
+                fed["native_rccl"] = {"error": "timed out after %.0f s (watchdog) in: %s; the torch.distributed figures "
+                                               "above stand; exit status 3" % (NATIVE_WATCHDOG_S, native_stage[0])}
+            sys.stderr.write("bench.py: rank %d: native RCCL leg hung in %s; exiting with status 3\n" % (rank, native_stage[0]))
+            sys.stderr.flush()
             emit()
-            os._exit(0)
+            os._exit(3)
 
-        dog = threading.Timer(120.0, bail)
+        dog = threading.Timer(NATIVE_WATCHDOG_S, bail)
         dog.daemon = True
         dog.start()
         from licos_amd import federation
+        res = None
         try:
             with federation.NativeComm() as comm:
-                fed["native_rccl"] = {sched: time_blend(native=comm, schedule=sched) for sched in ("ring", "direct")}
-                fed["native_rccl"]["what"] = "licos_allreduce_weighted / licos_allreduce_weighted_direct: the blend as one C-ABI call"
+                res = {}
+                for sched in ("ring", "direct"):
+                    native_stage[0] = "licos_allreduce_weighted%s (timing loop)" % ("_direct" if sched == "direct" else "")
+                    res[sched] = time_blend(native=comm, schedule=sched)
+                res["what"] = "licos_allreduce_weighted / licos_allreduce_weighted_direct: the blend as one C-ABI call"
                 # cross-check: the native path leaves the same state as torch.distributed's
+                native_stage[0] = "cross-check against torch.distributed"
                 probe = fs.flat[:1024].clone()
                 federation.weighted_average_(fs, 1.0 / world)
                 a = fs.flat[:1024].clone()
                 fs.flat[:1024] = probe
                 federation.weighted_average_(fs, 1.0 / world, native=comm, schedule="direct")
-                fed["native_rccl"]["max_abs_diff_vs_torch"] = float((fs.flat[:1024] - a).abs().max())
+                res["max_abs_diff_vs_torch"] = float((fs.flat[:1024] - a).abs().max())
+                native_stage[0] = "NativeComm.__exit__ (licos_comm_destroy)"
         except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
-            fed["native_rccl"] = {"error": str(e)[:300]}
+            res = {"error": str(e)[:300]}
         dog.cancel()
+        with emit_lock:
+            native_done[0] = True
+            if not emitted[0]:
+                fed["native_rccl"] = res
     emit()
 
     if world > 1:

@@ -290,6 +290,14 @@ def hyper_fast_path(net, batch):
     return (not ops.host_coder_preferred(batch)) and net.gaussian_conditional.coder_image() is not None
 
 
+def hyper_retry_chunk(chunk, ny):
+    """Chunk size of the worst-case-capacity retry (cap_words = 2 ny + 8): licos_rans_encode_records addresses its word
+    sink with 32-bit byte offsets, (cap + 1) * streams * 4 < 2^32 - an incompressible batch of M = 320 latents at 512^2
+    would not fit at the default 2048 tiles per chunk."""
+    cap = 2 * ny + 8
+    return max(1, min(chunk, ((1 << 32) - 1) // (4 * (cap + 1))))
+
+
 def compress_hyper(net, x, chunk=512, cap_words=None):
     """ScaleHyperprior.compress ([CAI] models/google.py) for a large batch, either precision: per chunk the four
     transforms run on the main stream, then ONE throughput kernel turns (y, scales) into per-symbol encoder records
@@ -354,7 +362,7 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
         if cap_words is not None:
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del queued
-        return compress_hyper(net, x, chunk=chunk, cap_words=2 * ny + 8)
+        return compress_hyper(net, x, chunk=hyper_retry_chunk(chunk, ny), cap_words=2 * ny + 8)
     for ci in range(min(CODER_STREAMS, len(segments))):
         main.wait_stream(_stream(dev, "coder%d" % ci))
     main.wait_stream(copy)
@@ -421,7 +429,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
     _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
                                                            status=status, off_offset=0))
     z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
-    yup = _upload(ystrs, pieces, dev, id_base=64)
+    yup = _upload(ystrs, pieces, dev, id_base=len(pieces))  # staging slots behind the z pieces': no slot is shared in a call
     fp16 = net.precision == "fp16"
     st = engine.stages(net.g_s)
     cout = st[-1][0].out_channels

@@ -37,9 +37,10 @@ class FlatState:
             raise ValueError("no floating state to average")
         dev = tensors[0][1].device
         total = sum(v.numel() for _, v in tensors)
-        # the allocation is padded so that it splits into equal chunks for any power-of-two world up to 64 (the direct
-        # schedule ships one chunk per peer); `flat` is the live part: state + the coefficient element
-        self.alloc = torch.zeros(-(-(total + 1) // 64) * 64, device=dev, dtype=torch.float32)
+        # the allocation is padded so that it splits into equal chunks for ANY world up to 64 (the direct schedule ships
+        # one chunk of ceil(n / world) elements per peer: at most n + world - 1 in all - a multiple of 64 alone is enough
+        # for power-of-two worlds only); `flat` is the live part: state + the coefficient element
+        self.alloc = torch.zeros(-(-(total + 1) // 64) * 64 + 64, device=dev, dtype=torch.float32)
         self.flat = self.alloc[: total + 1]
         self.keys = []
         off = 0

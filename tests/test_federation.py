@@ -94,3 +94,28 @@ def test_shard_range_partitions_exactly(total, world):
     assert covered == list(range(total))
     sizes = [federation.shard_range(total, r, world)[1] - federation.shard_range(total, r, world)[0] for r in range(world)]
     assert max(sizes) - min(sizes) <= 1
+
+
+def _tiny_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = torch.nn.Linear(9, 7, bias=False)  # 63 elements + the coefficient = 64: a bucket that is a multiple of 64
+        with torch.no_grad():
+            net.weight.fill_(float(rank + 1))
+        fs = federation.FlatState(net)
+        assert fs.flat.numel() % 64 == 0 and fs.flat.numel() % world != 0
+        federation.weighted_average_(fs, 1.0 / world, schedule="direct")
+        torch.save(net.weight.detach().clone(), out.format(rank=rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_schedule_on_a_bucket_of_64_with_three_ranks(tmp_path):
+    """The direct schedule ships ceil(n / world) elements per peer; for a world that does not divide 64 a bucket padded
+    to a multiple of 64 only is too short (n = 64, world = 3 needs 66).  FlatState pads by a further 64."""
+    out = str(tmp_path / "t{rank}.pt")
+    mp.spawn(_tiny_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    for r in range(3):
+        assert torch.allclose(torch.load(out.format(rank=r)), torch.full((7, 9), 2.0), atol=1e-6)

@@ -368,3 +368,37 @@ def test_band_sized_end_stage_queries_and_argument_checks():
                  lambda: lib.licos_nchw_f32_to_hwc_pad_f16(one, one, 1, 4, 16, 16, None)):
         assert call() == -1  # LICOS_EINVAL
         assert lib.licos_last_error()
+
+
+def test_spawner_returns_a_failing_ranks_status(capsys):
+    """bench.py --gpus N (bare): a rank that gives up with a non-zero status - the native-RCCL watchdog exits 3 after
+    printing what it has - must become the spawner's status, the other ranks are stopped, and rank 0's line is relayed."""
+    import argparse
+    import sys
+    import bench
+    code = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+            "if r == 0:\n"
+            "    print('{\"partial\": true}', flush=True)\n"
+            "    sys.exit(3)\n"
+            "time.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    status = bench.spawn_workers(argparse.Namespace(gpus=3), limit_s=30.0, cmd=[sys.executable, "-c", code])
+    assert status == 3
+    assert time.monotonic() - t0 < 25  # the sleeping ranks were stopped, not waited for
+    assert '{"partial": true}' in capsys.readouterr().out
+    ok = bench.spawn_workers(argparse.Namespace(gpus=2), limit_s=30.0, cmd=[sys.executable, "-c", "pass"])
+    assert ok == 0
+
+
+def test_hyper_retry_chunk_keeps_the_word_sink_below_4_gb():
+    """compress_hyper's worst-case retry (cap_words = 2 ny + 8) at M = 320, 512^2 tiles: 2048 streams x 655 369 words
+    x 4 B = 5.4 GB would be refused by licos_rans_encode_records (32-bit sink offsets); the retry shrinks the chunk."""
+    from licos_amd import codec
+    ny = 320 * 32 * 32
+    c = codec.hyper_retry_chunk(2048, ny)
+    assert 1 <= c < 2048 and (2 * ny + 8 + 1) * c * 4 < 2 ** 32 and (2 * ny + 8 + 1) * (c + 1) * 4 >= 2 ** 32
+    assert codec.hyper_retry_chunk(2048, 192 * 32 * 32) == 2048  # M = 192: 3.2 GB, fits as it is
+    assert codec.hyper_retry_chunk(4, 10 ** 9) == 1

@@ -53,7 +53,7 @@ struct Img {
 };
 
 // DMA: 0 none, 1 all pieces at the step's start, 2 one piece per item (an item = one A fragment's MFMAs)
-template <int WAVES, int DMA, bool EPI>
+template <int WAVES, int DMA, bool EPI, bool STAG = false, int PRIO = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void duo(const half8 *__restrict__ src, long src_gran, _Float16 *y, int nimg, unsigned long long *stamps,
                                                      int nsteps) {
   using I = Img<WAVES>;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void duo(const half8 *__restrict__ s
 #pragma unroll
   for (int n = 0; n < NT; ++n) base[n] = h * I::HALF + (wave * 2 + n + 1) * RS + r + 1;
   int cur = 0, nepi = 0;
+  if (PRIO) __builtin_amdgcn_s_setprio(PRIO);  // K loop above the epilogue: the matrix wave wins the SIMD's issue arbitration
   for (int st = 0; st < nsteps; ++st) {
     half8 *buf = s + cur * I::BUF;
     half8 *nb = s + (cur ^ 1) * I::BUF;
@@ -136,7 +137,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void duo(const half8 *__restrict__ s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     cur ^= 1;
-    if (EPI && (st & 7) == 7) {
+    // STAG: workgroups reach their epilogues at different steps (identical programs started together otherwise stay in
+    // lockstep - and two workgroups of a CU would both be in their epilogues at once)
+    const int stag = STAG ? (int)((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) & 7u) : 0;
+    if (EPI && ((st + stag) & 7) == 7) {
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
       // one phase's epilogue: the lane's two output pixels of a 128 x 128 x-split map, image chosen per (workgroup, epilogue)
       const int img = (int)((blockIdx.x * 131u + (unsigned)nepi * 17u) % (unsigned)nimg);
       long pix[NT];
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void duo(const half8 *__restrict__ s
       tile8_epilogue<MT, NT, EPI_IGDN>(acc, s_gamma, s_beta + 128, y + (size_t)img * 128 * 128 * 128, (size_t)128 * 128, 8, pix, lane);
       acc_init();
       ++nepi;
+      if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     }
   }
   float sum = 0.f;
@@ -167,9 +173,9 @@ struct Variant {
   int waves;
 };
 
-template <int WAVES, int DMA, bool EPI>
+template <int WAVES, int DMA, bool EPI, bool STAG = false, int PRIO = 0>
 static void launch(const half8 *src, long gran, _Float16 *y, int nimg, unsigned long long *stamps, int nsteps, int grid, hipStream_t st) {
-  auto k = duo<WAVES, DMA, EPI>;
+  auto k = duo<WAVES, DMA, EPI, STAG, PRIO>;
   static bool once = false;
   if (!once) {
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, Img<WAVES>::LDS));
@@ -207,6 +213,11 @@ int main(int argc, char **argv) {
       {"8 waves x 1 WG/CU, DMA start + EPILOGUE  ", launch<8, 1, true>, 8},  {"4 waves x 2 WG/CU, DMA start + EPILOGUE  ", launch<4, 1, true>, 4},
       {"8 waves x 1 WG/CU, DMA/item + EPILOGUE   ", launch<8, 2, true>, 8},  {"4 waves x 2 WG/CU, DMA/item + EPILOGUE   ", launch<4, 2, true>, 4},
       {"8 waves x 1 WG/CU, no DMA + EPILOGUE     ", launch<8, 0, true>, 8},  {"4 waves x 2 WG/CU, no DMA + EPILOGUE     ", launch<4, 0, true>, 4},
+      {"4 waves x 2 WG/CU, no DMA + EPI STAGGERED", launch<4, 0, true, true>, 4}, {"4 waves x 2, DMA start + EPI STAGGERED   ", launch<4, 1, true, true>, 4},
+      {"4 waves x 2, DMA/item + EPI STAGGERED    ", launch<4, 2, true, true>, 4}, {"8 waves x 1, DMA/item + EPI STAGGERED    ", launch<8, 2, true, true>, 8},
+      {"4 x 2, no DMA + EPI STAG, K loop prio 1  ", launch<4, 0, true, true, 1>, 4}, {"4 x 2, DMA/item + EPI STAG, K loop prio 1", launch<4, 2, true, true, 1>, 4},
+      {"4 x 2, no DMA + EPI STAG, K loop prio 3  ", launch<4, 0, true, true, 3>, 4}, {"4 x 2, DMA/item + EPI STAG, K loop prio 3", launch<4, 2, true, true, 3>, 4},
+      {"4 x 2, DMA/item + EPI no stag, prio 1    ", launch<4, 2, true, false, 1>, 4}, {"8 x 1, DMA/item + EPI, K loop prio 1     ", launch<8, 2, true, false, 1>, 8},
   };
   const int NV = sizeof(vs) / sizeof(vs[0]);
   std::vector<std::vector<float>> ms(NV);

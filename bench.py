@@ -318,16 +318,32 @@ def extras(args, net, x, dev):
         net.chunk = chunk16
         net.set_precision("fp16")
         torch.cuda.empty_cache()
-    # 1-channel (raw split) and 13-channel (raw merged) models, and one whole granule as the reference feeds it
+    # BASELINE configs[2]: bmshj2018_factorized q = 5 on single Sentinel-2 bands (raw split), and the same model family
+    # on the 13 merged bands; plus one whole granule as the reference feeds it.  Weights: the repo's own training
+    # recipe when a checkpoint is shipped (licos_amd/weights/factorized_q5_c{1,13}.pth.tar), else seeded trained-like ones.
+    from licos_amd import checkpoint
     configs = {}
     for cin, kind, b in ((1, "s2", 4096), (13, "s2-merged", 2048)):
         torch.manual_seed(42)
-        n2 = licos_amd.get_model("bmshj2018-factorized", False, cin, args.quality).to(dev).eval().set_precision("fp16")
+        n2 = licos_amd.get_model("bmshj2018-factorized", False, cin, 5).to(dev).eval().set_precision("fp16")
         n2.chunk = args.chunk
-        with torch.no_grad():
-            synthetic.make_trained_like(n2, seed=0)
+        wf = os.path.join(ROOT, "licos_amd", "weights", "factorized_q5_c%d.pth.tar" % cin)
+        if args.weights == "trained" and os.path.exists(wf):
+            wnote = "trained: " + str(checkpoint.load_checkpoint(wf, n2).get("recipe", os.path.basename(wf)))[:160]
+        else:
+            with torch.no_grad():
+                synthetic.make_trained_like(n2, seed=0)
+            wnote = "synthetic trained-like (seeded)"
         xb = synthetic.tiles(b, cin, 256, seed=7, kind=kind, device=dev)
-        configs["%dch" % cin] = dict(timed_codec(n2, xb, 3)[0], tiles=b)
+        res, c2, d2 = timed_codec(n2, xb, 3, split=True)
+        res.update(tiles=b, quality=5, weights=wnote,
+                   bpp_actual=round(8.0 * sum(len(s_) for s_ in c2["strings"][0]) / (b * 256 * 256), 4),
+                   psnr_db=round(licos_amd.metrics.compute_psnr(d2["x_hat"], xb), 3))
+        del c2, d2
+        if not args.no_cpu_baseline:  # "matched": the same 4 tiles through the CPU oracle on the same weights
+            sd2 = {k: v.detach().cpu().float() for k, v in n2.state_dict().items()}
+            res["quality_match"] = quality_match(n2, sd2, xb[:4].contiguous())
+        configs["%dch" % cin] = res
         if cin == 1:
             g = synthetic.tiles(1, 1, 2592, seed=11, kind="s2", device=dev)[:, :, :2304, :].contiguous()  # raw_utils.py:131
             one, c, d = timed_codec(n2, g, 3, split=True)  # eval_script.py:138-165: ONE image, one rANS stream of 4.5 M symbols

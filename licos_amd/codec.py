@@ -81,7 +81,8 @@ class PackedStrings(list):
     def still_packed(self):
         # element-wise comparison in C: identical objects short-cut on identity (a few tens of microseconds for
         # 16384 tiles), a replaced entry is compared by content - so an equal copy is fine and anything else is not
-        return (len(self) == len(self._built_with) and sum(n for _, n, _, _ in self.segments) == len(self)
+        # (the segments cover the device-coded tiles: a prefix of the list when the host coded the call's tail)
+        return (len(self) == len(self._built_with) and sum(n for _, n, _, _ in self.segments) <= len(self)
                 and tuple(self) == self._built_with)
 
 
@@ -89,23 +90,85 @@ def _chunks(total, size):
     return [(s, min(size, total - s)) for s in range(0, total, size)]
 
 
+# ---- split placement of the serial coder --------------------------------------------------------------------------------
+# A device coder launch lasts n_symbols x (latency of one rANS step) whatever the number of streams: ~145 ns per symbol
+# encoding, ~115 ns decoding (7.1 / 5.6 ms for a 256^2 tile's 49 152 symbols).  Inside a long call that is hidden under
+# the neighbouring chunks' transforms except ONCE per call - the last chunk's encode, the first chunk's decode - and it is
+# most of a call of a thousand tiles.  The host cores run the same coder (csrc/host_rans.cpp, bit-identical streams) at
+# ~1.8 / ~3.2 ns per symbol and thread: in the time of one device launch T threads code  T x (device ns) / (host ns)  tiles
+# (16 threads: ~1100 encoding, ~490 decoding).  So the tiles at the exposed end of a call go to the host, in sub-chunks
+# that pipeline with their transforms, and the device launch they run beside covers the rest.  LICOS_HOST_SPLIT=0
+# switches the split off (A/B); LICOS_HOST_ENC_NS / LICOS_HOST_DEC_NS override the host figures.
+HOST_SPLIT = os.environ.get("LICOS_HOST_SPLIT", "1") != "0"
+DEV_NS = {"enc": 145.0, "dec": 115.0}
+HOST_NS = {"enc": float(os.environ.get("LICOS_HOST_ENC_NS", "1.8")), "dec": float(os.environ.get("LICOS_HOST_DEC_NS", "3.2"))}
+# tiles per host thread and sub-chunk: 16 threads x 16 = 256 tiles = 50 MB of int32 symbols per transfer (a 25 MB
+# device-to-host copy runs at 15 GB/s on these boxes, a 150 MB one at 53: tools/split_probe.py)
+HOST_SUB = 16
+# Symbols of the host's tiles cross PCIe through a device buffer and the copy engines (default), or by the quantise /
+# dequantise kernels' own stores and loads on the page-locked staging buffer (LICOS_ZERO_COPY=1; measured equal for small
+# batches and slower at 1024 tiles: 13.2 vs 10.9 ms)
+ZERO_COPY = os.environ.get("LICOS_ZERO_COPY", "0") == "1"
+
+
+def host_capacity(direction):
+    """Tiles the host cores code in the time of ONE device coder launch (independent of the stream length)."""
+    return max(0, int(0.85 * ops.host_threads() * DEV_NS[direction] / HOST_NS[direction]))
+
+
+def host_share(batch, direction):
+    """How many tiles of a call of `batch` tiles the host codes.  Everything up to the host's capacity for the direction
+    (a thousand tiles encoding, five hundred decoding at 16 threads: the device coder's launch latency alone is longer
+    than the host takes); of a decode call of up to four times that, its first `capacity` tiles - the synthesis
+    transform starts on them while the one device launch the call needs anyway covers the rest; nothing of larger calls.
+    Measured and left out: the exposed end of LARGE calls (the last thousand tiles of a 16 384-tile compress, the first
+    five hundred of its decompress) - worth 3 - 5 ms of 200 on a quiet host, but this thread blocks in the host coder
+    while it should be queueing device work, and on a loaded shared host (one of the two boxes probed: a host step 5 - 8 x
+    slower than nominal) the same split COST 14 ms (profiles/r04_split_probe_box1.log / _box2.log)."""
+    if ops.HOST_CODER == "0":
+        return 0
+    if ops.HOST_CODER == "1" or ops.host_coder_preferred(batch):
+        return batch
+    if not HOST_SPLIT:
+        return 0
+    cap = host_capacity(direction)
+    if batch <= cap:
+        return batch
+    if direction == "dec" and batch <= 4 * cap:
+        return cap
+    return 0
+
+
+_pinned = {}
+
+
+def _pinned_i32(role, rows, cols):
+    """A reusable page-locked int32 [rows, cols] staging area per role (page-locked allocations cost milliseconds)."""
+    need = rows * cols
+    buf = _pinned.get(role)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 18) * 5 // 4, dtype=torch.int32, pin_memory=True)
+        _pinned[role] = buf
+    return buf[:need].view(rows, cols)
+
+
 def compress_chunked(net, x, chunk=1024, cap_words=None):
-    """FactorizedPrior.compress for any batch size and either precision (`net.g_a` dispatches on it)."""
+    """FactorizedPrior.compress for any batch size and either precision (`net.g_a` dispatches on it).  Tiles
+    [0, B - H) go through the device coder in pipeline chunks, the last H = host_share(B) tiles through the host coder in
+    sub-chunks (see "split placement" above); the strings do not depend on the placement."""
     eb = net.entropy_bottleneck
     cdf, cdf_len, offset, table = eb.coder_tables()
     if x.dtype != torch.float32 or x.dim() != 4:
         raise ValueError("licos_amd: compress expects a float32 (B, C, H, W) tensor")
     x = x.contiguous()
     B = x.shape[0]
-    if ops.host_coder_preferred(B):
-        # a handful of tiles, or one whole granule: one GPU lane per stream would take ~8 / ~16 ms per 49152 symbols
-        # whatever the batch; the host cores code such a batch in a fraction of that (entropy_models._compress_host)
-        y = net.g_a(x)
-        return {"strings": [eb.compress(y)], "shape": y.size()[-2:]}
+    n_host = host_share(B, "enc")
+    n_dev = B - n_host
     dev = x.device
     main = torch.cuda.current_stream(dev)
     side = _stream(dev, "coder")
     copy = _stream(dev, "copy")
+    hcopy = _stream(dev, "hostsym")
     med = eb.medians_vec()
     sec = _Section()
     sec.mark("c.start")
@@ -117,19 +180,19 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
     # symbols - and only the LAST launch of a call is exposed: measured, the step did not move.  LICOS_EB_RECORDS=1 switches.
     records = _EB_RECORDS and eb.coder_image() is not None
     queued = []  # every tensor another stream touches stays referenced here until its chunk is drained
-    for (s0, n) in _chunks(B, chunk):
+    for (s0, n) in _chunks(n_dev, chunk):
         y = net.g_a(x[s0:s0 + n])  # MFMA chain, main stream
         if shape is None:
             shape = tuple(y.shape[-2:])
             nsym, plane = y[0].numel(), y[0, 0].numel()
             if not records:
-                sym = torch.empty((nsym, B), device=dev, dtype=torch.int32)
+                sym = torch.empty((nsym, n_dev), device=dev, dtype=torch.int32)
             if cap_words is None:
                 cap_words = nsym // 2 + 64
         if records:
             keep = ops.eb_encode_prepare(y.contiguous(), med, table, cdf_len, offset, cdf.shape[1])
         else:
-            ops.eb_quantize(y, med, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=B, sym_offset=s0)
+            ops.eb_quantize(y, med, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=n_dev, sym_offset=s0)
             keep = y
         ready = torch.cuda.Event()
         ready.record(main)
@@ -138,24 +201,54 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
             if records:
                 words, nwords, status = ops.rans_encode_records(keep[0], keep[1], cap_words)
             else:
-                words, nwords, status = ops.rans_encode_batch(sym, 1, B, nsym, plane, cdf, cdf_len, offset, table, cap_words,
+                words, nwords, status = ops.rans_encode_batch(sym, 1, n_dev, nsym, plane, cdf, cdf_len, offset, table, cap_words,
                                                               n, sym_offset=s0)
             coded = torch.cuda.Event()
             coded.record(side)
         queued.append((s0, n, keep, words, nwords, status, coded))
+    # the host's tiles: transforms + quantise on the main stream behind the device chunks, symbols [stream][position]
+    # to a page-locked buffer on the copy stream, one event per sub-chunk
+    host_q, stage = [], None
+    if n_host:
+        sub = max(1, HOST_SUB * ops.host_threads())
+        for (t0, m) in _chunks(n_host, sub):
+            y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
+            if shape is None:
+                shape = tuple(y.shape[-2:])
+                nsym, plane = y[0].numel(), y[0, 0].numel()
+            if stage is None:
+                stage = _pinned_i32("enc", n_host, nsym)
+            if ZERO_COPY:
+                ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
+                landed = torch.cuda.Event()
+                landed.record(main)
+                host_q.append((t0, m, y, landed))
+                continue
+            hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
+            ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            # (a stream of its own: on the drains' copy stream these copies - which wait for the END of the main stream's
+            # work - would sit in front of every device chunk's length / byte transfers)
+            with torch.cuda.stream(hcopy):
+                hcopy.wait_event(ready)
+                stage[t0:t0 + m].copy_(hsym, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(hcopy)
+            host_q.append((t0, m, hsym, landed))
     sec.mark("c.queue transforms+encode")
-    # drain chunk by chunk on the copy stream while later chunks are still in flight
     strings = [None] * B
     segments = []
     overflow = False
-    for qi in range(len(queued)):
+
+    def drain(qi):
+        """One device chunk's strings: lengths, compaction, D2H, bytes - on the copy stream, while later work is in flight."""
         (s0, n, keep, words, nwords, status, coded) = queued[qi]
         with torch.cuda.stream(copy):
             copy.wait_event(coded)
             meta = torch.cat((nwords, status)).cpu().numpy()  # synchronises the copy stream only
             if meta[n]:
-                overflow = True
-                break
+                return True
             off = np.zeros(n + 1, dtype=np.int64)
             np.cumsum(meta[:n].astype(np.int64) * 4, out=off[1:])
             total = int(off[-1])
@@ -165,10 +258,25 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
             host_t.copy_(packed, non_blocking=True)
             copy.synchronize()
         queued[qi] = None  # the chunk's records (20 B per symbol) and word scratch go back to the allocator
-        del keep, words, nwords, status
         mv = memoryview(host_t.numpy())
         strings[s0:s0 + n] = [bytes(mv[off[i]:off[i + 1]]) for i in range(n)]
         segments.append((s0, n, host_t, off))
+        return False
+
+    # every device chunk but the last, then the host's sub-chunks (the last device launch runs beside them), then the last
+    for qi in range(len(queued) - 1):
+        if drain(qi):
+            overflow = True
+            break
+    if n_host and not overflow:
+        hcdf, hlen, hoff, htable = eb.coder_tables_host()
+        for (t0, m, hsym, landed) in host_q:
+            landed.synchronize()
+            out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
+            strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
+        del host_q
+    if queued and not overflow:
+        overflow = drain(len(queued) - 1)
     if overflow:
         torch.cuda.synchronize(dev)
         if cap_words >= 2 * nsym + 8:
@@ -177,20 +285,21 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
         return compress_chunked(net, x, chunk=chunk, cap_words=2 * nsym + 8)
     main.wait_stream(side)
     main.wait_stream(copy)
+    main.wait_stream(hcopy)
     sec.mark("c.drain (lengths, compact, D2H, bytes)")
     return {"strings": [PackedStrings(strings, segments)], "shape": torch.Size(shape)}
 
 
 def decompress_chunked(net, strings, shape, chunk=1024):
+    """FactorizedPrior.decompress.  The first H = host_share(B) tiles are decoded by the host cores in sub-chunks - the
+    synthesis transform starts on them about a millisecond into the call - while the device decodes the others (every
+    device launch is queued before the host starts); see "split placement" above."""
     eb = net.entropy_bottleneck
     cdf, cdf_len, offset, _ = eb.coder_tables()
     assert isinstance(strings, list) and len(strings) == 1
     strs = strings[0]
     B = len(strs)
-    if ops.host_coder_preferred(B):
-        y_hat = eb.decompress(list(strs), shape)
-        x_hat = net.g_s(y_hat)
-        return {"x_hat": x_hat.clamp_(0, 1)}
+    n_host = host_share(B, "dec")
     dev = cdf.device
     C = cdf.shape[0]
     h, w = int(shape[0]), int(shape[1])
@@ -200,7 +309,8 @@ def decompress_chunked(net, strings, shape, chunk=1024):
     med = eb.medians_vec()
     sec = _Section()
     sec.mark("d.start")
-    sym = torch.empty((nsym, B), device=dev, dtype=torch.int32)
+    n_dev = B - n_host
+    sym = torch.empty((nsym, n_dev), device=dev, dtype=torch.int32) if n_dev else None  # device-decoded tiles, [position][stream]
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     image = eb.coder_image() if _EB_IMAGE else None  # the image decoder (csrc/rans_gc.hip), channel pattern as shared rows
     rows = eb.channel_rows(plane) if image is not None else None
@@ -208,28 +318,58 @@ def decompress_chunked(net, strings, shape, chunk=1024):
     cout = st[-1][0].out_channels
     up = 2 ** len(st)
     x_hat = torch.empty((B, cout, h * up, w * up), device=dev, dtype=torch.float32)
-    # chunk list with each chunk's packed bytes: straight from compress()'s page-locked segments, or re-packed
-    if isinstance(strs, PackedStrings) and strs.still_packed():
-        pieces = [(s0, n, host_t, off) for (s0, n, host_t, off) in strs.segments]
-    else:
-        pieces = [(s0, n, None, None) for (s0, n) in _chunks(B, chunk)]
+    # device pieces (first tile, count, packed bytes, offsets) over tiles [n_host, B): straight from compress()'s
+    # page-locked segments where they cover them, re-packed otherwise
+    pieces = []
+    if n_dev:
+        covered = n_host
+        if isinstance(strs, PackedStrings) and strs.still_packed():
+            for (s0, n, host_t, off) in strs.segments:
+                if s0 + n <= covered or s0 > covered:
+                    continue
+                lo = covered - s0
+                pieces.append((covered, n - lo, host_t, off[lo:]))
+                covered = s0 + n
+        pieces += [(covered + t0, m, None, None) for (t0, m) in _chunks(B - covered, chunk)]
+        # a device launch lasts as long for 100 streams as for 4096: neighbours that fit one chunk together (the tiles the
+        # host encoded, behind the last packed segment) share a launch - their bytes are uploaded one after the other
+        merged = []
+        for pc in pieces:
+            if merged and merged[-1][1] + pc[1] <= chunk:
+                merged[-1] = (merged[-1][0], merged[-1][1] + pc[1], merged[-1][2] + [pc])
+            else:
+                merged.append((pc[0], pc[1], [pc]))
+        pieces = merged
     start = torch.cuda.Event()
     start.record(main)
     side.wait_event(start)
     events = []
     keep = []
-    for (s0, n, host_t, off) in pieces:
+    nslot = 0
+    for (s0, n, parts) in pieces:
         with torch.cuda.stream(side):
-            if host_t is not None:
-                data = host_t[: max(int(off[-1]), 4)].to(dev, non_blocking=True)
-                byte_off = torch.from_numpy(off).to(dev, non_blocking=True)
-            else:  # a staging buffer per piece, no sync here: the call's final status read orders everything
-                data, byte_off = eb.pack_strings(strs[s0:s0 + n], dev, slot=len(keep))
+            ups = []
+            for (p0, pn, host_t, off) in parts:
+                if host_t is not None:
+                    lo, hi = int(off[0]), int(off[-1])
+                    ups.append((host_t[lo: max(hi, lo + 4)].to(dev, non_blocking=True), torch.from_numpy(off - lo).to(dev, non_blocking=True)))
+                else:  # a staging buffer per part, no sync here: the call's final status read orders everything
+                    ups.append(eb.pack_strings(strs[p0:p0 + pn], dev, slot=nslot))
+                    nslot += 1
+            if len(ups) == 1:
+                data, byte_off = ups[0]
+            else:  # (every string is a whole number of 32-bit words: the parts concatenate without padding)
+                base, offs = 0, []
+                for (d_, o_) in ups:
+                    offs.append(o_[:-1] + base)
+                    base += int(d_.numel())
+                data = torch.cat([d_ for (d_, _) in ups])
+                byte_off = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
             if image is not None:
-                ops.rans_decode_image(data, byte_off, rows, nsym, image[0], image[1], sym, 1, B, n, status=status, sym_offset=s0,
-                                      rows_shared=True)
+                ops.rans_decode_image(data, byte_off, rows, nsym, image[0], image[1], sym, 1, n_dev, n, status=status,
+                                      sym_offset=s0 - n_host, rows_shared=True)
             else:
-                ops.rans_decode_batch(data, byte_off, 1, B, nsym, plane, cdf, cdf_len, offset, sym, n, sym_offset=s0,
+                ops.rans_decode_batch(data, byte_off, 1, n_dev, nsym, plane, cdf, cdf_len, offset, sym, n, sym_offset=s0 - n_host,
                                       status=status, off_offset=0)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -237,16 +377,38 @@ def decompress_chunked(net, strings, shape, chunk=1024):
         events.append(ev)
     sec.mark("d.queue H2D+decode")
     fp16 = net.precision == "fp16"
-    for (s0, n, _, _), ev in zip(pieces, events):
-        main.wait_event(ev)
+
+    def synthesise(s0, n, symbols, stride_b, stride_i, sym_offset=0):
         if fp16:
             y_blk = torch.zeros((n, (C + 15) // 16, h, w, 16), device=dev, dtype=torch.float16) if C % 16 else \
                 torch.empty((n, C // 16, h, w, 16), device=dev, dtype=torch.float16)
-            ops.eb_dequantize(sym, 1, B, med, n, C, h, w, want_nchw=False, blk16=y_blk, sym_offset=s0)
+            ops.eb_dequantize(symbols, stride_b, stride_i, med, n, C, h, w, want_nchw=False, blk16=y_blk, sym_offset=sym_offset)
             engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
         else:  # the parity path: fp32 NCHW latents, y_hat = symbol + median exactly as the reference's decompress
-            y_hat = ops.eb_dequantize(sym, 1, B, med, n, C, h, w, sym_offset=s0)
+            y_hat = ops.eb_dequantize(symbols, stride_b, stride_i, med, n, C, h, w, sym_offset=sym_offset)
             x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
+
+    # the host's tiles, sub-chunk by sub-chunk: decode (this thread blocks, the device decoders run), upload, synthesise
+    if n_host:
+        hcdf, hlen, hoff, _ = eb.coder_tables_host()
+        stage = _pinned_i32("dec", n_host, nsym)
+        sub = max(1, HOST_SUB * ops.host_threads())
+        for (t0, m) in _chunks(n_host, sub):
+            part = strs[t0:t0 + m]
+            lens = np.fromiter((len(b_) for b_ in part), dtype=np.int64, count=m)
+            byte_off = np.zeros(m + 1, dtype=np.int64)
+            np.cumsum(lens, out=byte_off[1:])
+            data = np.frombuffer(b"".join(part), dtype=np.uint8)
+            _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
+            if bad != 0:
+                torch.cuda.synchronize(dev)  # nothing of this call may still be reading its buffers when the exception unwinds
+                raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+            hsym = stage[t0:t0 + m] if ZERO_COPY else stage[t0:t0 + m].to(dev, non_blocking=True)
+            synthesise(t0, m, hsym, nsym, 1)
+            keep.append((hsym,))
+    for (s0, n, _), ev in zip(pieces, events):
+        main.wait_event(ev)
+        synthesise(s0, n, sym, 1, n_dev, sym_offset=s0 - n_host)
     sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")

@@ -34,6 +34,10 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _is_pinned_host(t):
+    return t is not None and (not t.is_cuda) and t.is_pinned() and t.is_contiguous()
+
+
 def _f32(t):
     if t.dtype != torch.float32:
         raise ValueError(f"licos_amd: expected float32, got {t.dtype}")
@@ -490,7 +494,10 @@ def eb_quantize(y, medians, mode, noise=None, symbols=None, sym_stride_b=0, sym_
                 sym_offset=0):
     """mode: 'dequantize' | 'noise' | 'symbols'.  y: (B, C, *spatial) fp32.  `sym_offset`: element offset of
     this batch's first stream inside a larger interleaved symbol buffer."""
-    _dev(y, medians, noise, symbols)
+    # (`symbols` may be a page-locked host tensor: the kernel then stores across PCIe itself - hipHostMalloc memory is
+    # mapped into the device's address space - instead of a device buffer plus a copy engine transfer, which runs at
+    # 15 GB/s for the 10 - 50 MB of a small batch: tools/split_probe.py)
+    _dev(y, medians, noise, None if (symbols is not None and _is_pinned_host(symbols)) else symbols)
     b, c = y.shape[:2]
     hw = y[0, 0].numel()
     m = {"dequantize": 0, "noise": 1, "symbols": 2}[mode]
@@ -551,8 +558,9 @@ def mask_mul_f32(g, ref, mode):
 
 
 def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want_nchw=True, blk16=None, sym_offset=0):
-    _dev(symbols, medians, blk16)
-    y = torch.empty((b, c, h, w), device=symbols.device, dtype=torch.float32) if want_nchw else None
+    # (`symbols` may be a page-locked host tensor, read across PCIe by the kernel itself: see eb_quantize)
+    _dev(None if _is_pinned_host(symbols) else symbols, medians, blk16)
+    y = torch.empty((b, c, h, w), device=medians.device, dtype=torch.float32) if want_nchw else None
     rc = _lib.load().licos_eb_dequantize(_p_off(symbols, sym_offset), sym_stride_b, sym_stride_i, _p(medians), _p(y), _p(blk16),
                                          b, c, h, w, _stream())
     _lib.check(rc, "eb_dequantize")

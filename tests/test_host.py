@@ -402,3 +402,30 @@ def test_hyper_retry_chunk_keeps_the_word_sink_below_4_gb():
     assert 1 <= c < 2048 and (2 * ny + 8 + 1) * c * 4 < 2 ** 32 and (2 * ny + 8 + 1) * (c + 1) * 4 >= 2 ** 32
     assert codec.hyper_retry_chunk(2048, 192 * 32 * 32) == 2048  # M = 192: 3.2 GB, fits as it is
     assert codec.hyper_retry_chunk(4, 10 ** 9) == 1
+
+
+def test_host_share_of_a_call(monkeypatch):
+    """Split placement of the serial coder (codec.host_share): all of a small batch, the exposed end of a large one -
+    as many tiles as the host threads code during ONE device coder launch - and nothing when the host coder is off."""
+    from licos_amd import codec, ops
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    monkeypatch.setattr(ops, "host_threads", lambda: 16)
+    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    cap_e, cap_d = codec.host_capacity("enc"), codec.host_capacity("dec")
+    assert cap_e == int(0.85 * 16 * codec.DEV_NS["enc"] / codec.HOST_NS["enc"]) and 0 < cap_d < cap_e
+    for b in (1, 16, 64, 384):
+        assert codec.host_share(b, "enc") == b and codec.host_share(b, "dec") == b  # the host-only batches of rounds 2 - 3
+    assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(cap_d + 1, "dec") == cap_d  # split: the call's first tiles
+    assert codec.host_share(4 * cap_d, "dec") == cap_d and codec.host_share(4 * cap_d + 1, "dec") == 0
+    assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(cap_e + 1, "enc") == 0
+    assert codec.host_share(16384, "enc") == 0 and codec.host_share(16384, "dec") == 0  # large calls: device only
+    monkeypatch.setattr(codec, "HOST_SPLIT", False)
+    assert codec.host_share(1000, "enc") == 0 and codec.host_share(64, "enc") == 64
+    monkeypatch.setattr(ops, "HOST_CODER", "0")
+    assert codec.host_share(1, "enc") == 0 and codec.host_share(16384, "dec") == 0
+    monkeypatch.setattr(ops, "HOST_CODER", "1")
+    assert codec.host_share(5000, "enc") == 5000
+    monkeypatch.setattr(ops, "host_threads", lambda: 1)
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    assert codec.host_share(100, "dec") == codec.host_capacity("dec") < 64

@@ -40,18 +40,22 @@ __global__ void chain(uint64_t *out, uint32_t seed, long *cycles) {
   if (threadIdx.x == 0) { cycles[0] = t1 - t0; cycles[1] = m1 - m0; }
 }
 
+// (round 4: the same chains with only the lower 32 lanes of the wave active - does a half-empty wave64 issue a dependent
+// instruction sooner on the SIMD-32?)
 template <int OP>
 void run(const char *name) {
   uint64_t *out; long *cyc;
   hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 16);
-  chain<OP><<<1, 64>>>(out, 7, cyc);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipEventRecord(e0);
-  chain<OP><<<1, 64>>>(out, 7, cyc);
-  hipEventRecord(e1); hipDeviceSynchronize();
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  long h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
-  printf("%-34s %7.2f memtime-cycles/op  %7.2f ns/op (event)\n", name, (double)h[1] / (64.0 * REP), 1e6 * ms / (64.0 * REP));
+  for (int threads = 64; threads >= 32; threads -= 32) {
+    chain<OP><<<1, threads>>>(out, 7, cyc);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    chain<OP><<<1, threads>>>(out, 7, cyc);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+    printf("%-30s %2d lanes %7.2f memtime-cycles/op  %7.2f ns/op (event)\n", name, threads, (double)h[1] / (64.0 * REP), 1e6 * ms / (64.0 * REP));
+  }
   fflush(stdout);
 }
 

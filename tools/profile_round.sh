@@ -19,6 +19,10 @@ python3 $root/tools/kernel_summary.py $(find $out/fp32 -name "f_results.db" | he
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --batch 4096 --chunk 4096 > $out/pmc_$c.json 2> $out/pmc_$c.err || exit 1
 done
+# config 5's dominant kernel (the g_s[4]-shaped transposed conv at 128^2 -> 256^2, 2048 tiles per launch): HBM traffic
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_h_$c -- python3 $root/tools/hyper_probe.py 2048 2048 > $out/pmc_h_$c.log 2> $out/pmc_h_$c.err || exit 1
+done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 $root/tools/stage_bench.py 1024 > $out/pmc_mfma.log 2>&1 || exit 1
 cd $root
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
@@ -26,5 +30,7 @@ python tools/pmc_traffic.py $f $w "deconv5x5s2_mfma8_kernel" 4096 5242880 $out/p
 python tools/pmc_traffic.py $f $w "conv5x5s2_mfma8_kernel" 4096 5242880 $out/pmc_traffic_conv_a3.json
 python tools/pmc_traffic.py $f $w "conv5x5s2_first_raw_kernel" 4096 4980736 $out/pmc_traffic_first.json
 python tools/pmc_traffic.py $f $w "deconv5x5s2_rows_kernel" 4096 4980736 $out/pmc_traffic_rows.json
+fh=$(find $out/pmc_h_FETCH_SIZE -name "*counter_collection.csv" | head -1); wh=$(find $out/pmc_h_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/pmc_traffic.py $fh $wh "deconv5x5s2_mfma8_kernel" 2048 20971520 $out/pmc_traffic_hyper_deconv.json
 python tools/pmc_mfma.py $(find $out/pmc_mfma -name "*counter_collection.csv" | head -1) $out/pmc_mfma_busy.json
-rm -rf $out/stats $out/hyper $out/train $out/fp32 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma
+rm -rf $out/stats $out/hyper $out/train $out/fp32 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma $out/pmc_h_FETCH_SIZE $out/pmc_h_WRITE_SIZE

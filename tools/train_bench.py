@@ -2,7 +2,8 @@
 13 x 256 x 256 patches, lambda 1e-2, clip 1.0, Adam 1e-4 / aux Adam 1e-3) on the GPU (HIP forward and backward,
 fp32), next to the same step of the oracle under torch autograd on the CPU.
 
-  python tools/train_bench.py [batch=16] [channels=13] [steps=10] [cpu_steps=1]"""
+  python tools/train_bench.py [batch=16] [channels=13] [steps=10] [cpu_steps=1] [model=bmshj2018-factorized]
+(the CPU leg is the factorized oracle's: pass cpu_steps = 0 with another model)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import licos_amd
@@ -14,7 +15,8 @@ C = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 cpu_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
-net = licos_amd.get_model("bmshj2018-factorized", False, C, 1).to(dev).train()
+MODEL = sys.argv[5] if len(sys.argv) > 5 else "bmshj2018-factorized"
+net = licos_amd.get_model(MODEL, False, C, 1).to(dev).train()
 crit = licos_amd.RateDistortionLoss(lmbda=1e-2)
 opt = licos_amd.net_aux_optimizer(net, {"net": {"type": "Adam", "lr": 1e-4}, "aux": {"type": "Adam", "lr": 1e-3}})
 kind = "aid" if C == 3 else ("s2-merged" if C == 13 else "s2")

@@ -370,6 +370,7 @@ def extras(args, net, x, dev):
     out["configs"] = configs
     torch.cuda.empty_cache()
     out["train_step"] = train_step_ms(dev, steps=10)[0]
+    out["train_step_hyperprior"] = train_step_ms(dev, steps=10, model="bmshj2018-hyperprior")[0]
     return out
 
 
@@ -455,8 +456,9 @@ def hyperprior_grid(args, dev):
     return out
 
 
-def train_step_ms(dev, steps=10, world=1):
-    """cfg/raw_merged.toml's training step on the device (HIP forward and backward, fp32): licos/train.py:186-200."""
+def train_step_ms(dev, steps=10, world=1, model="bmshj2018-factorized"):
+    """cfg/raw_merged.toml's training step on the device (HIP forward and backward, fp32): licos/train.py:186-200.
+    `model`: licos/model_utils.py:20-24 admits bmshj2018-hyperprior as well."""
     import gc
     import torch
     import licos_amd
@@ -464,7 +466,7 @@ def train_step_ms(dev, steps=10, world=1):
     gc.collect()
     gc.freeze()  # the step is ~690 launches of host work: keep the collector off everything this process built so far
     torch.manual_seed(42)
-    net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1).to(dev).train()
+    net = licos_amd.get_model(model, False, 13, 1).to(dev).train()
     crit = licos_amd.RateDistortionLoss(lmbda=1e-2)
     opt = licos_amd.net_aux_optimizer(net, {"net": {"type": "Adam", "lr": 1e-4}, "aux": {"type": "Adam", "lr": 1e-3}})
     x = synthetic.tiles(16, 13, 256, seed=1, kind="s2-merged", device=dev)

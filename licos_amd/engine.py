@@ -29,12 +29,13 @@ stage_events = None
 def _timed(key, fn):
     if stage_events is None:
         return fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    out = fn()
-    e1.record()
-    stage_events.setdefault(key, []).append((e0, e1))
+    sink = ops.stage_event_sink = []  # filled by ops._launch around the stage's C call (not around its output allocation)
+    try:
+        out = fn()
+    finally:
+        ops.stage_event_sink = None
+    if sink:
+        stage_events.setdefault(key, []).append((sink[0][0], sink[-1][1]))
     return out
 
 

@@ -34,6 +34,23 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+# Optional device timing of the transform stages (engine._timed, bench.py): while `stage_event_sink` is a list, every
+# stage launch is bracketed by HIP events on the stream it is launched on - around the C call itself, so that the output
+# allocation in front of it (which may have to free cached blocks, and hipFree waits for the whole device) is outside.
+stage_event_sink = None
+
+
+def _launch(cfn, *args):
+    if stage_event_sink is None:
+        return cfn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = cfn(*args)
+    e1.record()
+    stage_event_sink.append((e0, e1))
+    return rc
+
+
 def _is_pinned_host(t):
     return t is not None and (not t.is_cuda) and t.is_pinned() and t.is_contiguous()
 
@@ -952,7 +969,7 @@ def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
     else:
         y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), ho, wo, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
-    rc = _lib.load().licos_conv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+    rc = _launch(_lib.load().licos_conv5x5s2_f16, _p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                          _p(yn), b, cin, h, w, cout, _stream())
     _lib.check(rc, "conv5x5s2_f16")
     return y
@@ -971,7 +988,7 @@ def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cou
     else:
         y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), ho, wo, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
-    rc = _lib.load().licos_deconv5x5s2_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+    rc = _launch(_lib.load().licos_deconv5x5s2_f16, _p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                            _p(yn), int(clamp01), b, cin, h, w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_f16")
     return y
@@ -1006,7 +1023,7 @@ def conv5x5s2_s2d_f16(x_s2d, w_packed, bias_padded, gdn_packed, epilogue, cin, c
     else:
         y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_s2d.device, dtype=torch.float16)
         yb, yn = y, None
-    rc = _lib.load().licos_conv5x5s2_s2d_f16(_p(x_s2d), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+    rc = _launch(_lib.load().licos_conv5x5s2_s2d_f16, _p(x_s2d), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                              _p(yn), b, cin, h, w, cout, _stream())
     _lib.check(rc, "conv5x5s2_s2d_f16")
     return y
@@ -1044,7 +1061,7 @@ def conv5x5s2_first_f16(x_hwc, w_packed, bias_padded, gdn_packed, epilogue, b, c
         raise ValueError("conv5x5s2_first_f16: input is not the buffer nchw_f32_to_hwc_pad_f16 makes for this shape")
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x_hwc.device, dtype=torch.float16)
-    rc = _lib.load().licos_conv5x5s2_first_f16(_p(x_hwc), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
+    rc = _launch(_lib.load().licos_conv5x5s2_first_f16, _p(x_hwc), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
                                                b, cin, h, w, cout, _stream())
     _lib.check(rc, "conv5x5s2_first_f16")
     return y
@@ -1058,7 +1075,7 @@ def conv5x5s2_first_nchw_f16(x, w_packed, bias_padded, gdn_packed, epilogue, cou
         raise ValueError("conv5x5s2_first_nchw_f16: needs a float32 image whose width is a multiple of 4")
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x.device, dtype=torch.float16)
-    rc = _lib.load().licos_conv5x5s2_first_nchw_f16(_p(x), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
+    rc = _launch(_lib.load().licos_conv5x5s2_first_nchw_f16, _p(x), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
                                                     b, cin, h, w, cout, _stream())
     _lib.check(rc, "conv5x5s2_first_nchw_f16")
     return y
@@ -1082,7 +1099,7 @@ def deconv5x5s2_fewch_f16(x_blk, w_packed, bias_padded, cin, cout, clamp01=False
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("deconv5x5s2_fewch_f16: input is not the blk16 fp16 layout of `cin` channels")
     y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
-    rc = _lib.load().licos_deconv5x5s2_fewch_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(y), int(clamp01), b, cin, h,
+    rc = _launch(_lib.load().licos_deconv5x5s2_fewch_f16, _p(x_blk), _p(w_packed), _p(bias_padded), _p(y), int(clamp01), b, cin, h,
                                                  w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_fewch_f16")
     return y
@@ -1106,7 +1123,7 @@ def deconv5x5s2_scatter_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("deconv5x5s2_scatter_f16: input is not the blk16 fp16 layout of `cin` channels")
     y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
-    rc = _lib.load().licos_deconv5x5s2_scatter_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
+    rc = _launch(_lib.load().licos_deconv5x5s2_scatter_f16, _p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
                                                    b, cin, h, w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_scatter_f16")
     return y
@@ -1130,7 +1147,7 @@ def deconv5x5s2_rows_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=No
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
         raise ValueError("deconv5x5s2_rows_f16: input is not the blk16 fp16 layout of `cin` channels")
     y = _out_nchw(out, (b, cout, 2 * h, 2 * w), x_blk.device)
-    rc = _lib.load().licos_deconv5x5s2_rows_f16(_p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
+    rc = _launch(_lib.load().licos_deconv5x5s2_rows_f16, _p(x_blk), _p(w_packed), _p(bias), _p(y), int(bool(clamp01)) | (2 if in_xsplit else 0),
                                                 b, cin, h, w, cout, _stream())
     _lib.check(rc, "deconv5x5s2_rows_f16")
     return y
@@ -1158,7 +1175,7 @@ def conv3x3s1_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
     else:
         y = torch.empty((b, (3 if epilogue & EPI_OUT_SPLIT3 else 1) * ((cout + 15) // 16), h, w, 16), device=x_blk.device, dtype=torch.float16)
         yb, yn = y, None
-    rc = _lib.load().licos_conv3x3s1_f16(_p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
+    rc = _launch(_lib.load().licos_conv3x3s1_f16, _p(x_blk), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(yb),
                                          _p(yn), b, cin, h, w, cout, _stream())
     _lib.check(rc, "conv3x3s1_f16")
     return y

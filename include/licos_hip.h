@@ -397,6 +397,14 @@ int licos_conv5x5s2_first_f16(const void *x_hwc_pad, const void *w_packed_first,
  * per-granule source choice, the workgroup interleaves and converts them LDS to LDS - no layout pass, bit-identical output. */
 int licos_conv5x5s2_first_nchw_f16(const float *x_nchw, const void *w_packed_first, const float *bias, const void *gdn_packed,
                                    int epilogue, void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream);
+/* The first analysis stage for 4 < Cin <= 16 bands (the 13 merged Sentinel-2 bands: /root/reference/licos/raw_image_folder.py:168-174,
+ * model_utils.py:31-37 re-sizes g_a[0] to them) on the NCHW fp32 image IN PLACE (W a multiple of 4; 33 .. 128 output
+ * channels): replaces licos_nchw_f32_to_blk16 + licos_conv5x5s2_f16 for these models, bit-identical output.  The
+ * workgroup fills the K loop's even / odd input-row planes itself - 16-byte loads of 4 pixels per band, converted and
+ * written as 4-channel pieces of the planes' granules in the steps in which the K loop does not read the plane - and
+ * walks a run of tiles with gamma / beta / bias resident.  w_packed: licos_pack_conv_w_f16 of the [Cout][Cin][5][5] weight. */
+int licos_conv5x5s2_first16_nchw_f16(const float *x_nchw, const void *w_packed, const float *bias, const void *gdn_packed,
+                                     int epilogue, void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream);
 
 /* Last synthesis stage (Cout <= 32, NCHW fp32 out): all four output phases per workgroup, weights stored compact
  * (only ceil-pow2(Cout) rows per fragment).  CompressAI FactorizedPrior.g_s[6], replaced per licos/model_utils.py:38-45. */

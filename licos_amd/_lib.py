@@ -90,6 +90,7 @@ SIGNATURES = {
     "licos_pack_conv_w_first_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_conv5x5s2_first_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_conv5x5s2_first_nchw_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_conv5x5s2_first16_nchw_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_packed_deconv_w_fewch_bytes": (_c.c_size_t, [_i, _i]),
     "licos_pack_deconv_w_fewch_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "licos_deconv5x5s2_fewch_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -1,0 +1,286 @@
+// First analysis stage g_a[0] for 4 < C <= 16 input bands (the 13 merged Sentinel-2 bands of raw_image_folder.py:168-174,
+// configs 3 - 5) on the NCHW fp32 image IN PLACE: Conv2d(C -> 128, 5x5, stride 2, padding 2) + GDN / ReLU, blk16 fp16 out.
+//
+// Until round 4 these models paid a layout pass first (licos_nchw_f32_to_blk16: 13.6 MB in, 8.4 MB out per 13 x 512^2
+// tile - 11 ms per 2048 tiles, HBM-bound) and then ran the generic 8-wave kernel (mfma_conv8.hip) on a one-chunk blk16
+// image, one tile per workgroup with every operand's first request exposed.  Here the same K loop (kernel rows over the
+// even / odd input-row planes, weights streamed per kernel row) and the same epilogue run on planes the workgroup fills
+// ITSELF from the fp32 image: a thread owns one (plane row, group of 4 pixels) position, loads the 16 bytes of each band
+// there (a group is entirely inside the image or entirely outside it: W a multiple of 4, tile origins multiples of 64),
+// and writes each pixel's bands as 8-byte pieces (4 channels) of the planes' [half][row][x-parity][x/2] granules - four
+// bands at a time, so that at most 8 loads (32 registers) are in flight beside the accumulators; channel slots C .. 15
+// are written as zeros.  A workgroup walks a run of tiles with gamma / beta / bias resident; the planes are single-
+// buffered and refilled in the steps in which the K loop does not read them (requested at a step's top, written behind
+// its MFMAs):
+//     steps ky=0, ky=2 (even plane): the ODD rows of this tile, bands 0-7 then 8-15
+//     steps ky=1, ky=3 (odd plane) : the EVEN rows of the NEXT tile, bands 0-7 then 8-15
+// Same MFMA order as the blk16 route (cin chunk, ky in 0 2 4 1 3, kx, channel tile), same fp16 rounding of the input:
+// the output is bit-identical to licos_nchw_f32_to_blk16 + licos_conv5x5s2_f16 (tests/test_gpu_fp16.py).
+#include <cstdlib>
+
+#include "mfma_deconv8.hpp"
+
+namespace licos {
+
+struct First16Args {
+  const float *x;      // NCHW fp32 [B][C][H][W]
+  const half8 *wp;     // licos_pack_conv_w_f16 of the [128][C][5][5] weight: [ky][kx][mt][64] A fragments (one cin chunk)
+  const float *bias, *beta;
+  const bf16x8 *gamma;
+  _Float16 *y_blk;
+  int B, C, H, W, Ho, Wo, Cout, tiles_x, tiles_y;
+};
+
+struct First16Geom {
+  static constexpr int MT = 4, NT = 2, TH = 16, TW = 32;
+  static constexpr int PWH = 36, ROWG = 2 * PWH;            // granules per (half, row): both x parities
+  static constexpr int NR_E = TH + 2, NR_O = TH + 1;        // even / odd input rows of a tile
+  static constexpr int EVEN_GRAN = 2 * NR_E * ROWG, ODD_GRAN = 2 * NR_O * ROWG;
+  static constexpr int W_GRAN = 5 * MT * 64, GAMMA_GRAN = MT * MT * 2 * 64;
+  static constexpr int SG = 18;                              // 4-pixel groups per band and row: columns 2 tx0 - 4 .. 2 tx0 + 67
+  static constexpr int LDS_BYTES = 16 * (EVEN_GRAN + ODD_GRAN + 2 * W_GRAN + GAMMA_GRAN) + 2 * 32 * MT * 4;
+  static_assert(NR_E * SG <= 512, "one (plane row, pixel group) position per thread");
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv5x5s2_first16_kernel(First16Args a, int run) {
+  using G = First16Geom;
+  constexpr int MT = G::MT, NT = G::NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_even = reinterpret_cast<half8 *>(smem);
+  half8 *s_odd = s_even + G::EVEN_GRAN;
+  half8 *s_wbuf = s_odd + G::ODD_GRAN;  // [2][W_GRAN]
+  bf16x8 *s_gamma = reinterpret_cast<bf16x8 *>(s_wbuf + 2 * G::W_GRAN);
+  float *s_bias = reinterpret_cast<float *>(s_gamma + G::GAMMA_GRAN);  // [32 MT] bias, [32 MT] beta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int tiles = a.tiles_x * a.tiles_y, runs = (tiles + run - 1) / run;
+  int b, item;
+  xcd_work_item(blockIdx.x, a.B, runs, b, item);
+  const int t_first = item * run, t_count = (t_first + run <= tiles) ? run : tiles - t_first;
+  const float *xb = a.x + (size_t)b * a.C * a.H * a.W;
+
+  // ---- raw rows -> planes --------------------------------------------------------------------------------------------
+  // thread tid < nrows * SG owns (plane row j, group g) of a plane; `half` = bands 8 half .. 8 half + 7 (two batches of 4)
+  const int rj = tid / G::SG, rg = tid - rj * G::SG;
+  const size_t band = (size_t)a.H * a.W;
+  struct Raw {
+    float4 v[8];
+  };
+  auto raw_load = [&](Raw &rw, int tile, int nrows, int parity, int half) {
+    const int iy = 2 * (tile / a.tiles_x) * G::TH - 2 + 2 * rj + parity, ix = 2 * (tile % a.tiles_x) * G::TW - 4 + 4 * rg;
+    const bool ok = rj < nrows && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const float *p = xb + (ok ? (size_t)iy * a.W + ix : 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = 8 * half + k;
+      rw.v[k] = (ok && c < a.C) ? *reinterpret_cast<const float4 *>(p + (size_t)c * band) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto raw_store = [&](const Raw &rw, half8 *plane, int nrows, int half) {
+    if (rj >= nrows) return;
+    // pixel p of the group is patch column 4 g + p - 2 = 2 xh + par: p = 0, 1 -> xh = 2 g - 1 (par 0, 1), p = 2, 3 -> xh = 2 g
+    unsigned char *gr = reinterpret_cast<unsigned char *>(plane + (half * nrows + rj) * G::ROWG + 2 * rg);
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const float4 &b0 = rw.v[4 * qq], &b1 = rw.v[4 * qq + 1], &b2 = rw.v[4 * qq + 2], &b3 = rw.v[4 * qq + 3];
+      const half4v p0 = {(_Float16)b0.x, (_Float16)b1.x, (_Float16)b2.x, (_Float16)b3.x};
+      const half4v p1 = {(_Float16)b0.y, (_Float16)b1.y, (_Float16)b2.y, (_Float16)b3.y};
+      const half4v p2 = {(_Float16)b0.z, (_Float16)b1.z, (_Float16)b2.z, (_Float16)b3.z};
+      const half4v p3 = {(_Float16)b0.w, (_Float16)b1.w, (_Float16)b2.w, (_Float16)b3.w};
+      unsigned char *q = gr + 8 * qq;
+      if (rg > 0) {
+        *reinterpret_cast<half4v *>(q - 16) = p0;
+        *reinterpret_cast<half4v *>(q + (G::PWH - 1) * 16) = p1;
+      }
+      *reinterpret_cast<half4v *>(q) = p2;
+      *reinterpret_cast<half4v *>(q + G::PWH * 16) = p3;
+    }
+  };
+
+  auto dma_w = [&](int ky, int buf) {  // one kernel row of A fragments: [kx][mt][64]
+    const half8 *wsrc = a.wp + (size_t)ky * (5 * MT * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < (5 * MT + 7) / 8; ++i) {
+      const int q = wave + 8 * i;
+      if (q < 5 * MT) glds16(wsrc + q * 64, s_wbuf + buf * G::W_GRAN + q * 64);
+    }
+  };
+
+  // resident operands, the first weights, zeroed planes (channel slots C .. 15 and the row tails are never written again)
+  dma_w(0, 0);
+  static_assert(MT == 4, "bias + beta = one 64-lane piece");
+  if (wave == 0) glds16((lane < 32 || EPI != EPI_GDN) ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias);
+  if (EPI == EPI_GDN) {
+#pragma unroll
+    for (int i = 0; i < (G::GAMMA_GRAN / 64 + 7) / 8; ++i) {
+      const int q = wave + 8 * i;
+      if (q < G::GAMMA_GRAN / 64) glds16(a.gamma + q * 64 + lane, s_gamma + q * 64);
+    }
+  }
+  Raw rw;
+  raw_load(rw, t_first, G::NR_E, 0, 0);
+  raw_store(rw, s_even, G::NR_E, 0);
+  raw_load(rw, t_first, G::NR_E, 0, 1);
+  raw_store(rw, s_even, G::NR_E, 1);
+
+  f32x16 acc[MT][NT];
+  auto acc_init = [&]() {  // accumulators start at the bias: register q of tile mt is channel 32mt + (q&3) + 8(q>>2) + 4h
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(s_bias + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt][4 * g + 0] = bv.x;
+          acc[mt][nt][4 * g + 1] = bv.y;
+          acc[mt][nt][4 * g + 2] = bv.z;
+          acc[mt][nt][4 * g + 3] = bv.w;
+        }
+      }
+  };
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  acc_init();
+
+  int base_e[NT], base_o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ty = wave * NT + nt;
+    base_e[nt] = h * (G::NR_E * G::ROWG) + ty * G::ROWG + r;
+    base_o[nt] = h * (G::NR_O * G::ROWG) + ty * G::ROWG + r;
+  }
+  const int Cout16 = (a.Cout + 15) >> 4;
+  _Float16 *y_img = a.y_blk + (size_t)b * Cout16 * a.Ho * a.Wo * 16;
+  // (Measured and not kept: the counted wait of mfma_first.hip around the epilogue - the next tile's second weight row
+  // requested before the stores, no raw rows in the first step, s_waitcnt vmcnt(16) behind it: 22.3 against 22.0 ms per
+  // 2048 tiles of 13 x 512^2.  Every step ends with vmcnt(0).)
+  int wcur = 0;
+  for (int t = 0; t < t_count; ++t) {
+    const int tile = t_first + t;
+#pragma unroll
+    for (int si = 0; si < 5; ++si) {
+      const int ky = (si < 3) ? 2 * si : 2 * si - 5;  // 0, 2, 4, 1, 3
+      // the next step's weights (the next tile's first kernel row behind the last step)
+      if (si < 4) dma_w((si + 1 < 3) ? 2 * (si + 1) : 2 * (si + 1) - 5, wcur ^ 1);
+      else if (t + 1 < t_count) dma_w(0, wcur ^ 1);
+      // raw rows travel through registers across the step's MFMAs: requested here, converted and written behind them
+      if (si < 2) raw_load(rw, tile, G::NR_O, 1, si);
+      if (si >= 3 && t + 1 < t_count) raw_load(rw, tile + 1, G::NR_E, 0, si - 3);
+      const half8 *s_patch = (si < 3) ? s_even : s_odd;
+      const half8 *s_w = s_wbuf + wcur * G::W_GRAN;
+      const int rowoff = (ky >> 1) * G::ROWG;
+      {
+        constexpr int NI = 5 * MT;
+        const int pb0 = ((si < 3) ? base_e[0] : base_o[0]) + rowoff, pb1 = ((si < 3) ? base_e[1] : base_o[1]) + rowoff;
+        half8 a_cur = s_w[lane], a_nxt = s_w[64 + lane], b_cur[NT], b_nxt[NT];
+        b_nxt[0] = b_cur[0] = s_patch[pb0];
+        b_nxt[1] = b_cur[1] = s_patch[pb1];
+        static_for<NI>([&](auto itc) {
+          constexpr int it = decltype(itc)::value, mt = it % MT, kx = it / MT;
+          constexpr bool more_a = it + 2 < NI, more_b = (mt == MT - 2) && (kx + 1 < 5);
+          constexpr int boff = ((kx + 1) & 1) * G::PWH + ((kx + 1) >> 1);
+          half8 a_nn = a_nxt;
+          if (more_a) a_nn = s_w[(it + 2) * 64 + lane];
+          if (more_b) {
+            b_nxt[0] = s_patch[pb0 + boff];
+            b_nxt[1] = s_patch[pb1 + boff];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, b_cur[nt], acc[mt][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, (more_a ? 1 : 0) + (more_b ? NT : 0), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+          a_cur = a_nxt;
+          a_nxt = a_nn;
+          if (mt == MT - 1) {
+            b_cur[0] = b_nxt[0];
+            b_cur[1] = b_nxt[1];
+          }
+        });
+      }
+      // the plane this step does not read takes the rows requested at its top (the odd plane is free in steps 0 - 2, the
+      // even one - for the next tile - in steps 3 and 4)
+      if (si < 2) raw_store(rw, s_odd, G::NR_O, si);
+      if (si >= 3 && t + 1 < t_count) raw_store(rw, s_even, G::NR_E, si - 3);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      wcur ^= 1;
+    }
+    const int oy0 = (tile / a.tiles_x) * G::TH, ox0 = (tile % a.tiles_x) * G::TW;
+    long pix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = oy0 + wave * NT + nt, ox = ox0 + r;
+      pix[nt] = (oy < a.Ho && ox < a.Wo) ? (long)oy * a.Wo + ox : -1;
+    }
+    tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_bias + 32 * MT, y_img, (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    if (t + 1 < t_count) acc_init();
+  }
+}
+
+template <int EPI>
+static int launch_first16(const First16Args &a, hipStream_t s) {
+  using G = First16Geom;
+  const int tiles = a.tiles_x * a.tiles_y;
+  // tiles per workgroup: the resident operands (gamma, bias, the first weights) and the first tile's exposed rows are paid
+  // once per run; short runs while the call has too few workgroups to fill the chip
+  static const int run_env = [] { const char *e = getenv("LICOS_FIRST16_RUN"); return e ? atoi(e) : 0; }();
+  long want = (long)a.B * tiles / 512;
+  want = want < 1 ? 1 : (want > 8 ? 8 : want);
+  const int run_max = run_env > 0 ? run_env : (int)want;
+  const int run = tiles >= run_max ? run_max : tiles;
+  auto kern = conv5x5s2_first16_kernel<EPI>;
+  LICOS_ENSURE_LDS(kern, G::LDS_BYTES);
+  const long blocks = (long)cdiv(tiles, run) * a.B;
+  LICOS_REQUIRE(blocks < (1L << 31), "conv5x5s2_first16_nchw_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), G::LDS_BYTES, s, a, run);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+}  // namespace licos
+
+using namespace licos;
+
+extern "C" {
+
+int licos_conv5x5s2_first16_nchw_f16(const float *x_nchw, const void *w_packed, const float *bias, const void *gdn_packed, int epilogue,
+                                     void *y_blk16, int B, int Cin, int H, int W, int Cout, void *stream) {
+  LICOS_REQUIRE(x_nchw && w_packed && bias && y_blk16, "conv5x5s2_first16_nchw_f16: null buffer");
+  LICOS_REQUIRE(B > 0 && Cin > 0 && Cin <= 16 && H > 0 && W > 0 && Cout > 32 && Cout <= 128,
+                "conv5x5s2_first16_nchw_f16: needs 1..16 input bands and 33..128 output channels (the four-tile weight packing)");
+  LICOS_REQUIRE(W % 4 == 0, "conv5x5s2_first16_nchw_f16: the width must be a multiple of 4 (16-byte granules of the fp32 rows); use "
+                            "licos_nchw_f32_to_blk16 + licos_conv5x5s2_f16 otherwise");
+  LICOS_REQUIRE(epilogue != EPI_GDN || gdn_packed, "conv5x5s2_first16_nchw_f16: the GDN epilogue needs packed gamma/beta");
+  LICOS_REQUIRE(((uintptr_t)x_nchw & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)y_blk16 & 15) == 0,
+                "conv5x5s2_first16_nchw_f16: buffers must be 16-byte aligned");
+  First16Args a{};
+  a.x = x_nchw;
+  a.wp = static_cast<const half8 *>(w_packed);
+  a.bias = bias;
+  a.gamma = static_cast<const bf16x8 *>(gdn_packed);
+  a.beta = gdn_packed ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(gdn_packed) + (size_t)4 * 4 * 2 * 1024) : bias;
+  a.y_blk = static_cast<_Float16 *>(y_blk16);
+  a.B = B;
+  a.C = Cin;
+  a.H = H;
+  a.W = W;
+  a.Ho = (H - 1) / 2 + 1;
+  a.Wo = (W - 1) / 2 + 1;
+  a.Cout = Cout;
+  a.tiles_x = cdiv(a.Wo, First16Geom::TW);
+  a.tiles_y = cdiv(a.Ho, First16Geom::TH);
+  LICOS_REQUIRE((long)a.Ho * a.Wo * ((Cout + 15) / 16) * 32 < (1L << 32), "conv5x5s2_first16_nchw_f16: an image's output must stay below 4 GB (32-bit store offsets)");
+  LICOS_REQUIRE((long)Cin * H * W < (1L << 30), "conv5x5s2_first16_nchw_f16: image too large");
+  hipStream_t s = as_stream(stream);
+  if (epilogue == EPI_GDN) return launch_first16<EPI_GDN>(a, s);
+  if (epilogue == EPI_NONE) return launch_first16<EPI_NONE>(a, s);
+  if (epilogue == EPI_RELU) return launch_first16<EPI_RELU>(a, s);
+  return fail(LICOS_EINVAL, "conv5x5s2_first16_nchw_f16: epilogue %d not supported (none, GDN, ReLU)", epilogue);
+}
+
+}  // extern "C"

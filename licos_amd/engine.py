@@ -46,7 +46,8 @@ def _pver(p):
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
 FIRST_ROWS = os.environ.get("LICOS_FIRST", "1") != "0"  # kernel-row first stage (1..3 bands) instead of the space-to-depth 3x3 form
 FIRST_RAW = os.environ.get("LICOS_FIRST_RAW", "1") != "0"  # ... reading the NCHW fp32 image in place (no layout pass) when W % 4 == 0
-ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
+ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"
+FIRST16 = os.environ.get("LICOS_FIRST16", "1") != "0"  # 5..16 bands: the first stage on the NCHW fp32 image in place (csrc/mfma_first16.hip)  # row-walking last stage (1..3 bands) instead of the scatter form
 
 
 def _packed_conv(m, s2d=False, fewch=False, first=False):
@@ -137,13 +138,18 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
                       and st[0][0].out_channels <= 128 and len(st) > 1 and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse)
                       and min(h0, w0) >= 16)
         first_raw = first_rows and FIRST_RAW and w0 % 4 == 0
-        if first_rows:
+        # 5..16 bands (the 13 merged Sentinel-2 bands) into 33..128 channels: in place as well, no blk16 layout pass
+        first16 = (FIRST16 and isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
+                   and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in and 4 < x.shape[1] <= 16
+                   and 32 < st[0][0].out_channels <= 128 and len(st) > 1
+                   and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse) and w0 % 4 == 0 and min(h0, w0) >= 16)
+        if first_rows or first16:
             s2d_first = False
-            cur = x.contiguous() if first_raw else ops.nchw_f32_to_hwc_pad_f16(x.contiguous())
+            cur = x.contiguous() if (first_raw or first16) else ops.nchw_f32_to_hwc_pad_f16(x.contiguous())
         else:
             cur = ops.nchw_f32_to_s2d_blk16(x.contiguous()) if s2d_first else ops.nchw_f32_to_blk16(x.contiguous(), abs_in)
     else:
-        first_rows = False
+        first_rows = first16 = False
         cur = x_blk
     xsplit = False  # layout of `cur`: blk16, or its x-split form (ops.EPI_OUT_XSPLIT) between two kernels that agree on it
 
@@ -184,6 +190,10 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
         gp = _packed_gdn(g) if isinstance(g, GDN) else None
         epi = ops.EPI_NONE if g is None else ops.EPI_RELU if g == "relu" else (ops.EPI_IGDN if g.inverse else ops.EPI_GDN)
         norm = gp is not None
+        if first16 and idx == 0:
+            key = ("conv", m.in_channels, m.out_channels, h0, w0, x.shape[0], norm)
+            cur = _timed(key, lambda: ops.conv5x5s2_first16_nchw_f16(cur, wp, bp, gp, epi, m.out_channels))
+            continue
         if first_rows and idx == 0:
             key = ("conv", m.in_channels, m.out_channels, h0, w0, x.shape[0], norm)
             if first_raw:

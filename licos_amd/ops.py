@@ -1081,6 +1081,21 @@ def conv5x5s2_first_nchw_f16(x, w_packed, bias_padded, gdn_packed, epilogue, cou
     return y
 
 
+def conv5x5s2_first16_nchw_f16(x, w_packed, bias_padded, gdn_packed, epilogue, cout):
+    """First analysis stage for 5..16 bands on the NCHW fp32 image in place (width a multiple of 4; csrc/mfma_first16.hip);
+    w_packed: pack_conv_w_f16 of the layer's weight.  Returns blk16 fp16."""
+    _dev(x, w_packed, bias_padded, gdn_packed)
+    b, cin, h, w = x.shape
+    if x.dtype != torch.float32 or w % 4:
+        raise ValueError("conv5x5s2_first16_nchw_f16: needs a float32 image whose width is a multiple of 4")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((b, (cout + 15) // 16, ho, wo, 16), device=x.device, dtype=torch.float16)
+    rc = _launch(_lib.load().licos_conv5x5s2_first16_nchw_f16, _p(x), _p(w_packed), _p(bias_padded), _p(gdn_packed), epilogue, _p(y),
+                 b, cin, h, w, cout, _stream())
+    _lib.check(rc, "conv5x5s2_first16_nchw_f16")
+    return y
+
+
 def pack_deconv_w_fewch_f16(w):
     _dev(w)
     cin, cout = w.shape[:2]

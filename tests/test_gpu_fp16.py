@@ -635,6 +635,69 @@ def test_first_stage_kernel_rows_equals_conv(cin, cout, h, w, epi):
             ops.conv5x5s2_first_nchw_f16(x.to(DEV), wp, bp, gp, e, cout)
 
 
+@pytest.mark.parametrize("cin,cout,h,w,epi", [(13, 128, 512, 512, "gdn"), (13, 128, 256, 256, "gdn"), (13, 128, 64, 64, "none"),
+                                               (13, 128, 70, 100, "gdn"), (5, 128, 37, 68, "relu"), (16, 96, 48, 96, "none"),
+                                               (13, 128, 16, 260, "gdn"), (8, 128, 33, 64, "none")])
+def test_first_stage_in_place_for_many_bands(cin, cout, h, w, epi):
+    """g_a[0] for 5..16 bands on the NCHW fp32 image in place (csrc/mfma_first16.hip: the 13 merged Sentinel-2 bands of
+    configs 3 - 5): same operands as torch-CPU conv2d (+ GDN / ReLU); bit-identical to the route it replaces - blk16 layout
+    pass + the 8-wave kernel - wherever that route runs the 8-wave kernel (same MFMA order); ragged tiles, odd heights,
+    runs of tiles that end inside an image; a tile's bits do not depend on the batch it is in."""
+    from licos_amd.layers import GDN
+    g = torch.Generator().manual_seed(cin * 11 + h)
+    nb = 2 if h * w > 100000 else 3
+    x = h16(torch.rand(nb, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 5, 5, generator=g) * 0.1)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=2).float()
+    wp = ops.pack_conv_w_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    gp, e, tol = None, ops.EPI_NONE, 2e-3  # fp16 output
+    if epi == "gdn":
+        sd = {}
+        om._gdn_init(sd, "g.", cout)
+        sd["g.gamma"] = sd["g.gamma"] + 0.03 * torch.rand(cout, cout, generator=g)
+        m = GDN(cout)
+        m.load_state_dict({k[2:]: v for k, v in sd.items()})
+        gp, e, tol = engine._packed_gdn(m.to(DEV)), ops.EPI_GDN, 4e-3
+        ref = om.gdn(ref, sd, "g.")
+    elif epi == "relu":
+        e, ref = ops.EPI_RELU, ref.clamp_min(0)
+    xd = x.to(DEV)
+    out = ops.conv5x5s2_first16_nchw_f16(xd, wp, bp, gp, e, cout)
+    got = ops.blk16_to_nchw_f32(out, cout)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < tol
+    assert torch.equal(ops.conv5x5s2_first16_nchw_f16(xd, wp, bp, gp, e, cout), out)  # deterministic
+    old = ops.conv5x5s2_f16(ops.nchw_f32_to_blk16(xd), wp, bp, gp, e, cin, cout)
+    assert rel_err(ops.blk16_to_nchw_f32(old, cout), got) < tol
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if ho % 16 == 0 and wo >= 32 and cout == 128 and epi == "gdn":
+        # the replaced route is the 8-wave kernel with the tile epilogue there (accumulators start at the bias, as here): the
+        # same bits.  (Without a norm that kernel adds the bias last: equal up to the fp32 summation order, checked above.)
+        assert torch.equal(old, out)
+    assert torch.equal(ops.conv5x5s2_first16_nchw_f16(xd[1:2].contiguous(), wp, bp, gp, e, cout), out[1:2])
+    with pytest.raises(ValueError):
+        ops.conv5x5s2_first16_nchw_f16(xd[:, :, :, : w - 2].contiguous(), wp, bp, gp, e, cout)  # W % 4
+
+
+def test_models_with_13_bands_take_the_in_place_first_stage(monkeypatch):
+    """The default fp16 path of a 13-band model runs g_a[0] through licos_conv5x5s2_first16_nchw_f16, and its output equals
+    the blk16-route's (LICOS_FIRST16=0) bit for bit."""
+    torch.manual_seed(3)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 13, 1).to(DEV).eval().set_precision("fp16")
+    x = torch.rand(2, 13, 256, 256, device=DEV)
+    calls = []
+    real = ops.conv5x5s2_first16_nchw_f16
+    monkeypatch.setattr(ops, "conv5x5s2_first16_nchw_f16", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        y = net.g_a(x)
+        assert calls
+        monkeypatch.setattr(engine, "FIRST16", False)
+        y_old = net.g_a(x)
+    assert torch.equal(y, y_old)
+
+
 def test_first_stage_kernel_rows_rejects_unsupported_shapes():
     with pytest.raises(ValueError):
         ops.pack_conv_w_first_f16(torch.zeros(128, 4, 5, 5, device=DEV))

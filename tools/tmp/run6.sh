@@ -1,0 +1,11 @@
+set -e
+timeout -k 10 600 python -m pytest tests/test_gpu_fp16.py -x -q -m gpu -k "many_bands or 13_bands" > gpurun_out/t6.log 2>&1 || { tail -60 gpurun_out/t6.log; exit 1; }
+tail -3 gpurun_out/t6.log
+for f in 1 0 1; do
+  LICOS_FIRST16=$f timeout -k 10 200 python tools/stage_bench.py 2048 13 2>&1 | grep -E "conv_13|total" | sed "s/^/first16=$f  /" >> gpurun_out/first16_ab2.log
+done
+cat gpurun_out/first16_ab2.log
+for f in 1 0; do
+  LICOS_FIRST16=$f timeout -k 10 300 python tools/hyper_probe.py 2048 2048 2>&1 | grep -E "iter 2|conv_13" | sed "s/^/first16=$f  /" >> gpurun_out/first16_hyper2.log
+done
+cat gpurun_out/first16_hyper2.log

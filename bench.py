@@ -180,9 +180,11 @@ def stage_entry(key, ms, launches):
         # HBM-side traffic from the PMC passes of the 3-band 256^2 launches (profiles/README.md), scaled to this launch size
         tfile = None
         if few_in and (cin, h, w) == (3, 256, 256):
-            tfile = "r03_pmc_traffic_first.json"
+            tfile = "r04_pmc_traffic_first.json"
         elif few_out and (cout, h, w) == (3, 128, 128):
-            tfile = "r03_pmc_traffic_rows.json"
+            tfile = "r04_pmc_traffic_rows.json"
+        elif few_in and (cin, h, w) == (13, 512, 512):
+            tfile = "r04_pmc_traffic_first16.json"
         if tfile and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             ent["traffic"] = tj["hbm_bytes_per_launch"] * b / tj["tiles_per_launch"]
@@ -608,15 +610,16 @@ def main():
                                              "(SURVEY.md 8(d): a tile's work is conv + GDN MACs x 2)",
                     "frac_conv_only": round(fl_conv / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                     "algorithmic_bytes_per_launch": 2 * (key[1] * key[3] * key[4] + key[2] * (key[3] * key[4] * (4 if key[0] == "deconv" else 0.25))) * LB,
-                    "power_note": "operand-data dependent (DVFS): the g_s[4] / g_a[2] launches measured 14.13 / 12.23 ms on random operands and "
-                                  "10.01 / 8.26 ms on all-zero ones, same instruction stream and traffic - profiles/r03_power_probe.log "
-                                  "(tools/power_probe.py)"}
+                    "power_note": "operand-data dependent (DVFS): the g_s[4] / g_a[2] launches measured 13.78 / 11.96 ms on random operands "
+                                  "(socket power 1320 - 1330 W mean, 1400 W peak, sclk 1.65 - 1.78 GHz: rocm-smi) and 10.02 / 8.32 ms on "
+                                  "all-zero ones (1100 - 1120 W, 2.39 GHz), same instruction stream and traffic - "
+                                  "profiles/r04_power_probe.log (tools/power_probe.py)"}
 
         # `roofline` = the DOMINANT kernel of the step (largest total time among the MFMA stages, full-size launches);
         # the north-star target kernel g_a[2] rides along as `roofline_g_a2`
-        names = {("conv", 128, 128, 128, 128): ("conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r03_pmc_traffic_conv_a3.json"),
+        names = {("conv", 128, 128, 128, 128): ("conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r04_pmc_traffic_conv_a3.json"),
                  ("deconv", 128, 128, 64, 64): ("deconv5x5s2_mfma8_kernel<4,IGDN> (g_s[4], 128->128 @64^2->128^2, 4 phases per workgroup)",
-                                               "r03_pmc_traffic_deconv_s4.json")}
+                                               "r04_pmc_traffic_deconv_s4.json")}
         full = {k: v for k, v in per_stage_ms.items() if k[5] == max(kk[5] for kk in per_stage_ms)}
         dom = max(full, key=lambda k: full[k] * len(events[k]))
         nm = names.get(dom[:5], ("%s_%d_%d_%dx%d" % dom[:5], "none"))

@@ -518,6 +518,54 @@ def test_fp16_codec_host_and_device_coder_agree(monkeypatch):
     assert torch.equal(dd, dh) and torch.equal(dd, dcross) and torch.equal(dd, dcross2)
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+def test_strings_and_tiles_do_not_depend_on_the_coder_placement(monkeypatch, precision):
+    """Split placement of the serial coder (codec.host_share): whichever share of a call the host codes - nothing, the
+    call's last tiles (compress) / first tiles (decompress), a share that ends inside a packed segment, everything - the
+    byte strings are the same and so are the decoded tiles; also when decompress is handed a plain list, and when the
+    tiles the host encoded ride behind the last packed segment in ONE device launch."""
+    from licos_amd import codec
+    from licos_amd.codec import PackedStrings
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=5, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision(precision)
+    net.update(force=True)
+    net.chunk = 16
+    x = om.synthetic_tiles(40, 3, 64, seed=33).to(DEV)
+    share = {"enc": 0, "dec": 0}
+    monkeypatch.setattr(codec, "host_share", lambda batch, direction: min(batch, share[direction]))
+    monkeypatch.setattr(codec, "HOST_SUB", 1)  # sub-chunks of a few tiles: several of them per call
+    monkeypatch.setattr(ops, "host_threads", lambda: 4)
+    with torch.no_grad():
+        c0 = net.compress(x)
+        ref_strings = [bytes(s_) for s_ in c0["strings"][0]]
+        ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
+        assert isinstance(c0["strings"][0], PackedStrings) and len(c0["strings"][0].segments) == 3
+        for enc, dec in ((12, 0), (12, 10), (12, 20), (3, 37), (40, 0), (40, 40), (0, 40), (0, 7)):
+            share["enc"], share["dec"] = enc, dec
+            c = net.compress(x)
+            assert [bytes(s_) for s_ in c["strings"][0]] == ref_strings, (enc, dec)
+            assert sum(n for _, n, _, _ in c["strings"][0].segments) == 40 - enc
+            for strings in (c["strings"], [[bytes(s_) for s_ in c["strings"][0]]]):
+                got = net.decompress(strings, c["shape"])["x_hat"]
+                assert torch.equal(got, ref), (enc, dec)
+        # chunks of 32: the 18 tiles left of the packed segment and the 12 the host encoded share one device launch
+        net.chunk = 32
+        share["enc"], share["dec"] = 12, 10
+        c = net.compress(x)
+        assert [bytes(s_) for s_ in c["strings"][0]] == ref_strings and len(c["strings"][0].segments) == 1
+        assert torch.equal(net.decompress(c["strings"], c["shape"])["x_hat"], ref)
+        net.chunk = 16
+    # a corrupt stream among the host's tiles raises like one among the device's
+    share["enc"], share["dec"] = 0, 10
+    bad = list(ref_strings)
+    bad[3] = bad[3][:8]
+    with torch.no_grad(), pytest.raises(ValueError):
+        net.decompress([bad], c0["shape"])
+
+
 def test_mutated_packed_strings_decode_what_the_list_holds(monkeypatch):
     """The list compress() returns may be edited by the caller (a corruption experiment, a swap between tiles): the
     packed host buffers it remembers are then stale and decompress must decode the list's bytes, including when the

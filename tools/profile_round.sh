@@ -32,5 +32,6 @@ python tools/pmc_traffic.py $f $w "conv5x5s2_first_raw_kernel" 4096 4980736 $out
 python tools/pmc_traffic.py $f $w "deconv5x5s2_rows_kernel" 4096 4980736 $out/pmc_traffic_rows.json
 fh=$(find $out/pmc_h_FETCH_SIZE -name "*counter_collection.csv" | head -1); wh=$(find $out/pmc_h_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_traffic.py $fh $wh "deconv5x5s2_mfma8_kernel" 2048 20971520 $out/pmc_traffic_hyper_deconv.json
+python tools/pmc_traffic.py $fh $wh "conv5x5s2_first16_kernel" 2048 30408704 $out/pmc_traffic_first16.json
 python tools/pmc_mfma.py $(find $out/pmc_mfma -name "*counter_collection.csv" | head -1) $out/pmc_mfma_busy.json
 rm -rf $out/stats $out/hyper $out/train $out/fp32 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma $out/pmc_h_FETCH_SIZE $out/pmc_h_WRITE_SIZE

@@ -276,10 +276,14 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
             break
     if n_host and not overflow:
         hcdf, hlen, hoff, htable = eb.coder_tables_host()
-        for (t0, m, hsym, landed) in host_q:
-            landed.synchronize()
-            out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
-            strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
+        try:
+            for (t0, m, hsym, landed) in host_q:
+                landed.synchronize()
+                out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
+                strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
+        except BaseException:
+            torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffer: let them land
+            raise
         del host_q
     if queued and not overflow:
         overflow = drain(len(queued) - 1)
@@ -409,7 +413,11 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             byte_off = np.zeros(m + 1, dtype=np.int64)
             np.cumsum(lens, out=byte_off[1:])
             data = np.frombuffer(b"".join(part), dtype=np.uint8)
-            _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
+            try:
+                _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
+            except BaseException:
+                torch.cuda.synchronize(dev)  # earlier sub-chunks' uploads still read the shared page-locked buffer
+                raise
             if bad != 0:
                 torch.cuda.synchronize(dev)  # nothing of this call may still be reading its buffers when the exception unwinds
                 raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")

@@ -25,6 +25,7 @@ CODER_STREAMS = 8  # side streams the hyperprior codec spreads its chunks' coder
 # Optional host-side section timing (tools/profile_step.py): when a dict, every section boundary
 # synchronises the device and accumulates wall-clock seconds.  None in production.
 timings = None
+host_trace = None  # dev probe: when a list, the host loops append ("enc", tiles, wait ms, coder ms, strings ms) / ("dec", tiles, join ms, coder ms, queue ms)
 
 
 # Optional device timing of the serial coder launches (bench.py): when a dict, each one is bracketed by HIP events on
@@ -90,18 +91,31 @@ def _chunks(total, size):
     return [(s, min(size, total - s)) for s in range(0, total, size)]
 
 
+def _ramp(total, first, size):
+    """Sub-chunks that double from `first` up to `size`: the host starts coding (or the synthesis transform starts) after
+    a few tiles' worth of work instead of a full sub-chunk's, and the later sub-chunks keep the transfers large."""
+    out, s0, m = [], 0, max(1, min(first, size))
+    while s0 < total:
+        n = min(m, total - s0)
+        out.append((s0, n))
+        s0 += n
+        m = min(size, 2 * m)
+    return out
+
+
 # ---- split placement of the serial coder --------------------------------------------------------------------------------
 # A device coder launch lasts n_symbols x (latency of one rANS step) whatever the number of streams: ~145 ns per symbol
 # encoding, ~115 ns decoding (7.1 / 5.6 ms for a 256^2 tile's 49 152 symbols).  Inside a long call that is hidden under
 # the neighbouring chunks' transforms except ONCE per call - the last chunk's encode, the first chunk's decode - and it is
 # most of a call of a thousand tiles.  The host cores run the same coder (csrc/host_rans.cpp, bit-identical streams) at
-# ~1.8 / ~3.2 ns per symbol and thread: in the time of one device launch T threads code  T x (device ns) / (host ns)  tiles
-# (16 threads: ~1100 encoding, ~490 decoding).  So the tiles at the exposed end of a call go to the host, in sub-chunks
+# ~1.8 / ~4 ns per symbol and thread: in the time of one device launch T threads code  T x (device ns) / (host ns)  tiles
+# (16 threads: ~1100 encoding, ~390 decoding: the decode figure is what the sub-chunk pipeline sustains - 256 tiles in 2.35 ms,
+# 32 in 0.5 ms - not the coder alone).  So the tiles at the exposed end of a call go to the host, in sub-chunks
 # that pipeline with their transforms, and the device launch they run beside covers the rest.  LICOS_HOST_SPLIT=0
 # switches the split off (A/B); LICOS_HOST_ENC_NS / LICOS_HOST_DEC_NS override the host figures.
 HOST_SPLIT = os.environ.get("LICOS_HOST_SPLIT", "1") != "0"
 DEV_NS = {"enc": 145.0, "dec": 115.0}
-HOST_NS = {"enc": float(os.environ.get("LICOS_HOST_ENC_NS", "1.8")), "dec": float(os.environ.get("LICOS_HOST_DEC_NS", "3.2"))}
+HOST_NS = {"enc": float(os.environ.get("LICOS_HOST_ENC_NS", "1.8")), "dec": float(os.environ.get("LICOS_HOST_DEC_NS", "4.0"))}
 # tiles per host thread and sub-chunk: 16 threads x 16 = 256 tiles = 50 MB of int32 symbols per transfer (a 25 MB
 # device-to-host copy runs at 15 GB/s on these boxes, a 150 MB one at 53: tools/split_probe.py)
 HOST_SUB = 16
@@ -212,36 +226,6 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
             coded = torch.cuda.Event()
             coded.record(side)
         queued.append((s0, n, keep, words, nwords, status, coded))
-    # the host's tiles: transforms + quantise on the main stream behind the device chunks, symbols [stream][position]
-    # to a page-locked buffer on the copy stream, one event per sub-chunk
-    host_q, stage = [], None
-    if n_host:
-        sub = max(1, HOST_SUB * ops.host_threads())
-        for (t0, m) in _chunks(n_host, sub):
-            y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
-            if shape is None:
-                shape = tuple(y.shape[-2:])
-                nsym, plane = y[0].numel(), y[0, 0].numel()
-            if stage is None:
-                stage = _pinned_i32("enc", n_host, nsym)
-            if ZERO_COPY:
-                ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
-                landed = torch.cuda.Event()
-                landed.record(main)
-                host_q.append((t0, m, y, landed))
-                continue
-            hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
-            ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            # (a stream of its own: on the drains' copy stream these copies - which wait for the END of the main stream's
-            # work - would sit in front of every device chunk's length / byte transfers)
-            with torch.cuda.stream(hcopy):
-                hcopy.wait_event(ready)
-                stage[t0:t0 + m].copy_(hsym, non_blocking=True)
-                landed = torch.cuda.Event()
-                landed.record(hcopy)
-            host_q.append((t0, m, hsym, landed))
     sec.mark("c.queue transforms+encode")
     strings = [None] * B
     segments = []
@@ -269,22 +253,70 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
         segments.append((s0, n, host_t, off))
         return False
 
-    # every device chunk but the last, then the host's sub-chunks (the last device launch runs beside them), then the last
+    # every device chunk but the last (the last device launch runs beside the host's share below)
     for qi in range(len(queued) - 1):
         if drain(qi):
             overflow = True
             break
+    # The host's tiles, a software pipeline in this thread: queue sub-chunk k's transforms + quantise (main stream) and
+    # the copy of its symbols [stream][position] to a page-locked buffer (a stream of its own), THEN code sub-chunk k - 1
+    # while the GPU works on k.  (Queueing everything first and coding afterwards cost a 1024-tile call 4.5 ms: a
+    # sub-chunk's ten launches are ~0.6 ms of Python, during which the host coder had nothing to do.)
     if n_host and not overflow:
         hcdf, hlen, hoff, htable = eb.coder_tables_host()
+        sub = max(1, HOST_SUB * ops.host_threads())
+        stage = None
+
+        def host_encode(entry):
+            (t0, m, _keep, landed) = entry
+            if host_trace is not None:
+                import time
+                w0 = time.perf_counter()
+            landed.synchronize()
+            if host_trace is not None:
+                w1 = time.perf_counter()
+            out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
+            if host_trace is not None:
+                w2 = time.perf_counter()
+            strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
+            if host_trace is not None:
+                host_trace.append(("enc", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
+
+        pending = None
         try:
-            for (t0, m, hsym, landed) in host_q:
-                landed.synchronize()
-                out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
-                strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
+            for (t0, m) in _ramp(n_host, 2 * ops.host_threads(), sub):
+                y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
+                if shape is None:
+                    shape = tuple(y.shape[-2:])
+                    nsym, plane = y[0].numel(), y[0, 0].numel()
+                if stage is None:
+                    stage = _pinned_i32("enc", n_host, nsym)
+                if ZERO_COPY:
+                    ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
+                    landed = torch.cuda.Event()
+                    landed.record(main)
+                    entry = (t0, m, y, landed)
+                else:
+                    hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
+                    ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    # (a stream of its own: on the drains' copy stream these copies would queue up behind / in front of
+                    # the device chunks' length and byte transfers)
+                    with torch.cuda.stream(hcopy):
+                        hcopy.wait_event(ready)
+                        stage[t0:t0 + m].copy_(hsym, non_blocking=True)
+                        landed = torch.cuda.Event()
+                        landed.record(hcopy)
+                    entry = (t0, m, hsym, landed)
+                if pending is not None:
+                    host_encode(pending)
+                pending = entry
+            if pending is not None:
+                host_encode(pending)
         except BaseException:
             torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffer: let them land
             raise
-        del host_q
     if queued and not overflow:
         overflow = drain(len(queued) - 1)
     if overflow:
@@ -402,31 +434,62 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             y_hat = ops.eb_dequantize(symbols, stride_b, stride_i, med, n, C, h, w, sym_offset=sym_offset)
             x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
 
-    # the host's tiles, sub-chunk by sub-chunk: decode (this thread blocks, the device decoders run), upload, synthesise
+    def synthesise_device_pieces():
+        for (s0, n, _), ev in zip(pieces, events):
+            main.wait_event(ev)
+            synthesise(s0, n, sym, 1, n_dev, sym_offset=s0 - n_host)
+
+    # The host's tiles, sub-chunk by sub-chunk: decode (this thread blocks, the device decoders run), upload, synthesise.
+    # When the call has device pieces as well, the host's tiles are synthesised on a stream of their own and the device
+    # pieces' transforms are queued on the main stream right after the FIRST host sub-chunk (whose launches packed the
+    # weights: the main stream waits for that event) - they start the moment their decode launch ends, while this
+    # thread is still decoding the host's later sub-chunks (queued behind the host loop they started 3 ms late).
     if n_host:
+        import contextlib
         hcdf, hlen, hoff, _ = eb.coder_tables_host()
         stage = _pinned_i32("dec", n_host, nsym)
         sub = max(1, HOST_SUB * ops.host_threads())
-        for (t0, m) in _chunks(n_host, sub):
+        hsyn = _stream(dev, "hostsyn") if pieces else None
+        if hsyn is not None:
+            hsyn.wait_event(start)
+        queued_device = not pieces
+        for (t0, m) in _ramp(n_host, 2 * ops.host_threads(), sub):
+            if host_trace is not None:
+                import time
+                w0 = time.perf_counter()
             part = strs[t0:t0 + m]
             lens = np.fromiter((len(b_) for b_ in part), dtype=np.int64, count=m)
             byte_off = np.zeros(m + 1, dtype=np.int64)
             np.cumsum(lens, out=byte_off[1:])
             data = np.frombuffer(b"".join(part), dtype=np.uint8)
+            if host_trace is not None:
+                w1 = time.perf_counter()
             try:
                 _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
             except BaseException:
                 torch.cuda.synchronize(dev)  # earlier sub-chunks' uploads still read the shared page-locked buffer
                 raise
+            if host_trace is not None:
+                w2 = time.perf_counter()
             if bad != 0:
                 torch.cuda.synchronize(dev)  # nothing of this call may still be reading its buffers when the exception unwinds
                 raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
-            hsym = stage[t0:t0 + m] if ZERO_COPY else stage[t0:t0 + m].to(dev, non_blocking=True)
-            synthesise(t0, m, hsym, nsym, 1)
+            with (torch.cuda.stream(hsyn) if hsyn is not None else contextlib.nullcontext()):
+                hsym = stage[t0:t0 + m] if ZERO_COPY else stage[t0:t0 + m].to(dev, non_blocking=True)
+                synthesise(t0, m, hsym, nsym, 1)
             keep.append((hsym,))
-    for (s0, n, _), ev in zip(pieces, events):
-        main.wait_event(ev)
-        synthesise(s0, n, sym, 1, n_dev, sym_offset=s0 - n_host)
+            if host_trace is not None:
+                host_trace.append(("dec", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
+            if not queued_device:
+                packed_ev = torch.cuda.Event()
+                packed_ev.record(hsyn)
+                main.wait_event(packed_ev)
+                synthesise_device_pieces()
+                queued_device = True
+        if hsyn is not None:
+            main.wait_stream(hsyn)
+    else:
+        synthesise_device_pieces()
     sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")

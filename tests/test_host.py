@@ -429,3 +429,24 @@ def test_host_share_of_a_call(monkeypatch):
     monkeypatch.setattr(ops, "HOST_CODER", "auto")
     monkeypatch.setattr(codec, "HOST_SPLIT", True)
     assert codec.host_share(3 * codec.host_capacity("dec") + 1, "dec") == codec.host_capacity("dec") < 64
+
+
+def test_host_capacity_follows_the_measured_host_rate(monkeypatch):
+    """codec._note_host_rate: a host that codes slower than nominal (a shared host under other tenants' load) shrinks the
+    share the next calls give it; a quiet one restores it; small sub-chunks and a faster-than-nominal host change nothing."""
+    from licos_amd import codec, ops
+    monkeypatch.setattr(ops, "host_threads", lambda: 16)
+    monkeypatch.setattr(codec, "_host_factor", {"enc": 1.0, "dec": 1.0})
+    cap0 = codec.host_capacity("enc")
+    nsym = 49152
+    codec._note_host_rate("enc", 8, nsym, 1.0)               # too few tiles to say anything
+    assert codec.host_capacity("enc") == cap0
+    codec._note_host_rate("enc", 256, nsym, 256 * nsym * 0.5e-9 / 16)   # faster than nominal: the factor stays 1
+    assert codec.host_capacity("enc") == cap0
+    for _ in range(6):
+        codec._note_host_rate("enc", 256, nsym, 256 * nsym * 9.0e-9 / 16)  # 5 x slower than the expected 1.8 ns
+    assert cap0 / 5.5 < codec.host_capacity("enc") < cap0 / 4.0
+    assert codec.host_capacity("dec") == int(0.85 * 16 * codec.DEV_NS["dec"] / codec.HOST_NS["dec"])  # per direction
+    for _ in range(10):
+        codec._note_host_rate("enc", 256, nsym, 256 * nsym * 1.8e-9 / 16)
+    assert codec.host_capacity("enc") >= cap0 - 2

@@ -449,4 +449,4 @@ def test_host_capacity_follows_the_measured_host_rate(monkeypatch):
     assert codec.host_capacity("dec") == int(0.85 * 16 * codec.DEV_NS["dec"] / codec.HOST_NS["dec"])  # per direction
     for _ in range(10):
         codec._note_host_rate("enc", 256, nsym, 256 * nsym * 1.8e-9 / 16)
-    assert codec.host_capacity("enc") >= cap0 - 2
+    assert codec.host_capacity("enc") >= 0.99 * cap0

@@ -152,13 +152,17 @@ def host_capacity(direction):
 
 def host_share(batch, direction):
     """How many tiles of a call of `batch` tiles the host codes.  Everything up to the host's capacity for the direction
-    (a thousand tiles encoding, five hundred decoding at 16 threads: the device coder's launch latency alone is longer
+    (a thousand tiles encoding, four hundred decoding at 16 threads: the device coder's launch latency alone is longer
     than the host takes); of a decode call of up to four times that, its first `capacity` tiles - the synthesis
     transform starts on them while the one device launch the call needs anyway covers the rest; nothing of larger calls.
-    Measured and left out: the exposed end of LARGE calls (the last thousand tiles of a 16 384-tile compress, the first
-    five hundred of its decompress) - worth 3 - 5 ms of 200 on a quiet host, but this thread blocks in the host coder
-    while it should be queueing device work, and on a loaded shared host (one of the two boxes probed: a host step 5 - 8 x
-    slower than nominal) the same split COST 14 ms (profiles/r04_split_probe_box1.log / _box2.log)."""
+    `capacity` follows the rate the host coder delivered in this process's recent calls (_note_host_rate).
+    Measured and left out, twice: the exposed end of LARGE calls (the last thousand tiles of a 16 384-tile compress, the
+    first four hundred of its decompress).  First form (all GPU work queued, then the host codes): -3 ms of 200 on a
+    quiet host, +14 ms on a loaded one (profiles/r04_split_probe_box1.log / _box2.log).  Second form (sub-chunk k queued
+    before k - 1 is coded, host tiles synthesised on their own stream, share sized by the measured host rate): 210.8 ms
+    per 16 384-tile step against 200.6 - 201.5 without it, twice each on one box - the host pipeline moves ~100 tiles per
+    ms where the device transforms 185, so a thousand tiles at the end of a call take longer through it than the 7-ms
+    device launch they were meant to hide."""
     if ops.HOST_CODER == "0":
         return 0
     if ops.HOST_CODER == "1" or ops.host_coder_preferred(batch):

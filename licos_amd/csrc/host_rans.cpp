@@ -171,7 +171,42 @@ void encode_streams(const int32_t *const (&sym)[K], const int32_t *const (&idx)[
       }
     }
   }
-  for (int i = planes ? -1 : n - 1; i >= 0; --i) {
+  bool indexed = !planes;
+  for (int k = 0; k < K; ++k) indexed = indexed && idx[k] != nullptr;
+  if (indexed) {
+    // explicit per-symbol rows (the scale hyperprior's y stream: the row follows the predicted scale and changes from one
+    // symbol to the next): the row's table pointer, range and offset are re-derived for EVERY symbol without a branch - a
+    // "did the row change" test mispredicts on a quarter of the symbols of a trained model
+    for (int i = n - 1; i >= 0; --i) {
+#pragma GCC unroll 8
+      for (int k = 0; k < K; ++k) {
+        if (__builtin_expect(bad[k], 0)) continue;
+        const int r = idx[k][(long)i * stride];
+        if (__builtin_expect((unsigned)r >= (unsigned)t.rows, 0)) { bad[k] = true; continue; }
+        const EncRec *e_row = enc + (size_t)r * t.cdf_stride;
+        const int maxv = t.cdf_len[r] - 2, o = t.offset[r];
+        if (__builtin_expect(maxv < 0, 0)) { bad[k] = true; continue; }
+        int value = sym[k][(long)i * stride] - o;
+        if (__builtin_expect((unsigned)value >= (unsigned)maxv, 0)) {
+          const uint32_t raw = value < 0 ? (uint32_t)(-2 * (int64_t)value - 1) : (uint32_t)(2 * ((int64_t)value - maxv));
+          int nb = 0;
+          while (nb < 8 && (raw >> (nb * BYPASS_BITS)) != 0) ++nb;
+          for (int j = nb - 1; j >= 0; --j) enc_bypass(x[k], out[k], (raw >> (j * BYPASS_BITS)) & BYPASS_MAX);
+          int val = nb, chunks = 0;
+          while (val >= BYPASS_MAX) { val -= BYPASS_MAX; ++chunks; }
+          enc_bypass(x[k], out[k], (uint32_t)val);
+          for (int c = 0; c < chunks; ++c) enc_bypass(x[k], out[k], BYPASS_MAX);
+          value = maxv;
+        }
+        const EncRec &e = e_row[value];
+        const uint32_t freq = e.freq ? e.freq : 65536u;
+        if (__builtin_expect(x[k] >= ((uint64_t)freq << 47), 0)) { out[k].put((uint32_t)x[k]); x[k] >>= 32; }
+        const uint64_t q = mulhi64(x[k], e.rcp) >> e.shift;
+        x[k] = x[k] + e.bias + q * (uint64_t)(65536u - freq);
+      }
+    }
+  }
+  for (int i = (planes || indexed) ? -1 : n - 1; i >= 0; --i) {
 #pragma GCC unroll 8
     for (int k = 0; k < K; ++k) {
       if (idx[k]) {
@@ -400,6 +435,52 @@ void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], in
         i0 = i + 1;
       }
     }
+  }
+  bool indexed = !planes;
+  for (int k = 0; k < K; ++k) indexed = indexed && idx[k] != nullptr;
+  if (indexed) {
+    // explicit per-symbol rows: every row-dependent quantity re-derived per symbol, no "row changed" branch (see encode)
+    for (int i = 0; i < n; ++i) {
+#pragma GCC unroll 8
+      for (int k = 0; k < K; ++k) {
+        if (__builtin_expect(done[k], 0)) continue;
+        const int r = idx[k][(long)i * stride];
+        if (__builtin_expect((unsigned)r >= (unsigned)t.rows || t.cdf_len[r] - 2 < 0, 0)) { rc[k] = -2; done[k] = true; continue; }
+        const int32_t *c_row = t.cdf + (size_t)r * t.cdf_stride;
+        const uint16_t *f_row = lut.first.data() + (size_t)r * 256;
+        const int ln = t.cdf_len[r], maxv = ln - 2, o = t.offset[r];
+        const uint32_t cf = (uint32_t)x[k] & 0xFFFF;
+        int s2 = f_row[cf >> 8];
+        while (s2 + 2 < ln && (uint32_t)c_row[s2 + 1] <= cf) ++s2;
+        const uint32_t start = (uint32_t)c_row[s2], range = (uint32_t)c_row[s2 + 1] - start;
+        x[k] = (uint64_t)range * (x[k] >> PREC) + cf - start;
+        if (__builtin_expect(x[k] < RANS_L, 0)) x[k] = (x[k] << 32) | in[k].get();
+        int value = s2;
+        if (__builtin_expect(s2 == maxv, 0)) {
+          int val = (int)dec_bypass(x[k], in[k]), nb = val;
+          while (val == BYPASS_MAX) {
+            val = (int)dec_bypass(x[k], in[k]);
+            nb += val;
+            if (in[k].overrun) break;
+          }
+          uint32_t raw = 0;
+          for (int j = 0; j < nb; ++j) {
+            const uint32_t d = dec_bypass(x[k], in[k]);
+            if (j < 8) raw |= d << (j * BYPASS_BITS);
+            if (in[k].overrun) break;
+          }
+          const int v = (int)(raw >> 1);
+          value = (raw & 1) ? -v - 1 : v + maxv;
+        }
+        sym[k][(long)i * stride] = value + o;
+        if (__builtin_expect(in[k].overrun, 0)) {
+          for (int j = i + 1; j < n; ++j) sym[k][(long)j * stride] = 0;
+          rc[k] = 1;
+          done[k] = true;
+        }
+      }
+    }
+    i0 = n;
   }
   for (int i = i0; i < n; ++i) {
 #pragma GCC unroll 8

@@ -48,3 +48,45 @@ for threads in sorted({1, T}):
     e, dd = sorted(enc)[len(enc) // 2], sorted(dec)[len(dec) // 2]
     print("threads %2d  B %d: encode %.3f ms = %.2f ns/symbol/thread, decode %.3f ms = %.2f ns/symbol/thread; %.3f bits/symbol"
           % (threads, B, 1e3 * e, 1e9 * e * threads / (B * n), 1e3 * dd, 1e9 * dd * threads / (B * n), 8.0 * nb.sum() / (B * n)))
+
+# ---- explicit per-symbol rows (the scale hyperprior's y stream: GaussianConditional tables, row = scale index) ----------
+hy = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 5)
+wf = os.path.join(os.path.dirname(licos_amd.__file__), "weights", "hyperprior_q5_c13.pth.tar")
+if os.path.exists(wf):
+    checkpoint.load_checkpoint(wf, hy)
+hy.update(force=True)
+gc_ = hy.gaussian_conditional
+gcdf = gc_._quantized_cdf.numpy().astype(np.int32)
+gcl = gc_._cdf_length.numpy().astype(np.int32)
+goff = gc_._offset.numpy().astype(np.int32)
+gtable = ops.rans_build_enc_table(gcdf, gcl)
+n2 = 192 * 32 * 32
+Bh = max(8, B // 4)
+# rows as the trained 13-band model uses them: 73 % row 0, the rest spread over rows 20 - 30
+rows = np.where(rng.random((Bh, n2)) < 0.73, 0, rng.integers(20, 31, size=(Bh, n2))).astype(np.int32)
+sym2 = np.empty((Bh, n2), dtype=np.int32)
+for r_ in np.unique(rows):
+    L = int(gcl[r_]) - 1
+    pmf = np.diff(gcdf[r_, : L + 1]).astype(np.float64)
+    pmf[-1] = 0
+    pmf /= pmf.sum()
+    m_ = rows == r_
+    sym2[m_] = rng.choice(L, size=int(m_.sum()), p=pmf) + goff[r_]
+for threads in sorted({1, T}):
+    enc, dec = [], []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        out, nb = ops.rans_encode_host(sym2, n2, 0, gcdf, gcl, goff, gtable, indexes=rows, nthreads=threads)
+        t1 = time.perf_counter()
+        data = np.concatenate([out[b, : nb[b]] for b in range(Bh)])
+        bo = np.concatenate(([0], np.cumsum(nb))).astype(np.int64)
+        t2 = time.perf_counter()
+        d, st = ops.rans_decode_host(data, bo, n2, 0, gcdf, gcl, goff, Bh, indexes=rows, nthreads=threads)
+        t3 = time.perf_counter()
+        if r:
+            enc.append(t1 - t0)
+            dec.append(t3 - t2)
+    assert st == 0 and np.array_equal(d, sym2)
+    e, dd = sorted(enc)[len(enc) // 2], sorted(dec)[len(dec) // 2]
+    print("explicit rows: threads %2d  B %d: encode %.3f ms = %.2f ns/symbol/thread, decode %.3f ms = %.2f ns/symbol/thread; %.3f bits/symbol"
+          % (threads, Bh, 1e3 * e, 1e9 * e * threads / (Bh * n2), 1e3 * dd, 1e9 * dd * threads / (Bh * n2), 8.0 * nb.sum() / (Bh * n2)))

@@ -97,6 +97,8 @@ def test_conv_two_images_per_pixel_tile(batch, cin, cout, h, w, relu):
 @pytest.mark.parametrize("cin,cout,h,w", [(192, 128, 16, 16), (192, 128, 4, 4), (128, 128, 32, 32), (128, 128, 64, 64),
                                            (128, 3, 32, 32), (128, 13, 20, 36), (128, 1, 16, 16), (128, 128, 11, 19),
                                            (128, 7, 9, 40), (192, 24, 8, 33),
+                                           # the 13-band last stage (16 x 16 x 32 kernel): odd width (8-byte stores), 9 and 16 channels
+                                           (128, 13, 9, 35), (128, 9, 33, 64), (128, 16, 16, 34),
                                            # the 8-wave kernel (input >= 16 x 32, <= 128 output channels): whole and ragged
                                            # 16 x 32 tiles, the bench geometry, a granule-shaped map, 96 channels
                                            (128, 128, 40, 80), (128, 128, 18, 35), (128, 96, 16, 32), (192, 128, 17, 64),

@@ -340,6 +340,32 @@ def test_shipped_operating_point_codes_images():
     assert float(esc) < 1e-3, float(esc)
 
 
+@pytest.mark.parametrize("cin,kind,min_psnr", [(1, "s2", 36.0), (13, "s2-merged", 33.0)])
+def test_shipped_q5_points_of_the_sentinel_configs(cin, kind, min_psnr):
+    """licos_amd/weights/factorized_q5_c{1,13}.pth.tar (BASELINE configs[2]: q = 5 on single bands / the 13 merged bands,
+    trained by tools/train_weights.py at lambda 0.025): held-out tiles through the fp16 codec - whose first stage for 13
+    bands reads the NCHW fp32 image in place - against the oracle on the same weights."""
+    import os
+    from licos_amd import checkpoint, synthetic
+    path = os.path.join(os.path.dirname(licos_amd.__file__), "weights", "factorized_q5_c%d.pth.tar" % cin)
+    net = licos_amd.get_model("bmshj2018-factorized", False, cin, 5).to(DEV).eval()
+    meta = checkpoint.load_checkpoint(path, net)
+    assert "recipe" in meta and meta["batch_idx"] >= 4000
+    x = synthetic.tiles(4, cin, 256, seed=100, kind=kind, device=DEV)
+    net.set_precision("fp16")
+    with torch.no_grad():
+        out = net(x)
+        c = net.compress(x)
+        d = net.decompress(c["strings"], c["shape"])
+    psnr = licos_amd.metrics.compute_psnr(d["x_hat"], x)
+    bpp = 8.0 * sum(len(s) for s in c["strings"][0]) / (4 * 256 * 256)
+    assert psnr > min_psnr and 0.02 < bpp < 1.5, (psnr, bpp)
+    sd = {k: v.detach().cpu().float() if v.dtype.is_floating_point else v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = om.forward(x.cpu(), sd)
+    assert abs(licos_amd.metrics.compute_bpp(out) - om.compute_bpp(ref)) < 2e-3 * om.compute_bpp(ref)
+    assert abs(licos_amd.metrics.compute_psnr(out["x_hat"].clamp(0, 1), x) - om.compute_psnr(ref["x_hat"].clamp(0, 1), x.cpu())) < 0.02
+
+
 def _real_crops():
     import os
     import numpy as np

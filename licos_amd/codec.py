@@ -136,12 +136,12 @@ _host_factor = {"enc": 1.0, "dec": 1.0}
 _EXPECT_NS = {"enc": 1.8, "dec": 3.0}  # coder time alone per symbol and thread, as the pipeline's sub-chunks see it on a quiet host
 
 
-def _note_host_rate(direction, tiles, nsym, seconds):
+def _note_host_rate(direction, tiles, nsym, seconds, expect_ns=None):
     threads = ops.host_threads()
     if tiles < 4 * threads or seconds <= 0:
         return
     ns = 1e9 * seconds * threads / (tiles * nsym)
-    f = max(1.0, ns / _EXPECT_NS[direction])
+    f = max(1.0, ns / (_EXPECT_NS[direction] if expect_ns is None else expect_ns))
     _host_factor[direction] = 0.5 * _host_factor[direction] + 0.5 * f
 
 
@@ -558,12 +558,43 @@ def hyper_retry_chunk(chunk, ny):
     return max(1, min(chunk, ((1 << 32) - 1) // (4 * (cap + 1))))
 
 
+HYPER_HOST_NS = {"enc": float(os.environ.get("LICOS_HYPER_HOST_ENC_NS", "4.2")),   # host coder with explicit per-symbol rows, ns per symbol
+                 "dec": float(os.environ.get("LICOS_HYPER_HOST_DEC_NS", "6.0"))}   # and thread (y + z streams, string handling included)
+HYPER_HOST_CODER_NS = {"enc": 3.6, "dec": 5.2}                                      # the y coder call alone (what _note_host_rate sees)
+HYPER_DEV_NS = {"enc": 159.0, "dec": 117.0}                                         # the device y coders' latency per symbol
+_hyper_share = {}
+
+
+def hyper_host_share(batch, direction="enc"):
+    """Tiles at the END of a compress_hyper / decompress_hyper call that the host codes (y and z streams): as many as the
+    host threads code during the ONE device launch of the y coder that is exposed per call (31 ms encoding, 23 ms
+    decoding a 512^2 tile's 196 608 symbols) - their transforms then run beside that launch instead of in front of /
+    behind it.  A scale-hyperprior tile is 37 us of transforms on the encode side and the host codes it in 59 us
+    (16 threads), so - unlike the factorized codec's large calls, section "split placement" above - the host keeps up
+    with the device for the length of that launch.  The count moves in steps of 4 x threads and only when the measured host
+    rate has moved it by a whole step (a change of the device chunks' sizes costs the caching allocator a round of
+    hipMalloc, 30 ms)."""
+    if ops.HOST_CODER == "0" or not HOST_SPLIT:
+        return 0
+    if "LICOS_HYPER_SHARE" in os.environ:  # dev probe
+        return min(int(os.environ["LICOS_HYPER_SHARE"]), batch // 3)
+    threads = ops.host_threads()
+    step = 4 * threads
+    cap = 0.85 * threads * HYPER_DEV_NS[direction] / (HYPER_HOST_NS[direction] * _host_factor[direction])
+    last = _hyper_share.get(direction)
+    if last is None or abs(cap - last) >= step:
+        last = _hyper_share[direction] = int(cap) // step * step
+    return max(0, min(last, batch // 3 // step * step))
+
+
 def compress_hyper(net, x, chunk=512, cap_words=None):
     """ScaleHyperprior.compress ([CAI] models/google.py) for a large batch, either precision: per chunk the four
     transforms run on the main stream, then ONE throughput kernel turns (y, scales) into per-symbol encoder records
     (licos_gc_encode_prepare) and the two serial coder kernels (z: plane coder, y: record coder) run on the side stream
     under the next chunk's transforms.  z_hat is round(z - median) + median computed directly: the reference obtains it
-    by decoding the z string it has just written, which returns exactly those integers."""
+    by decoding the z string it has just written, which returns exactly those integers.  The call's last
+    hyper_host_share(B) tiles are coded by the host cores (symbols and table rows [stream][position] over PCIe, sub-chunk
+    k queued before k - 1 is coded) while the last device launch runs."""
     eb, gc = net.entropy_bottleneck, net.gaussian_conditional
     zcdf, zlen, zoff, ztab = eb.coder_tables()
     ycdf, ylen, yoff, ytab = gc.coder_tables()
@@ -574,10 +605,13 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     dev = x.device
     main = torch.cuda.current_stream(dev)
     copy = _stream(dev, "copy")
+    hcopy = _stream(dev, "hostsym")
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
+    n_host = hyper_host_share(B) if cap_words is None else 0
+    n_dev = B - n_host
     queued, shape = [], None
-    for ci, (s0, n) in enumerate(_chunks(B, chunk)):
+    for ci, (s0, n) in enumerate(_chunks(n_dev, chunk)):
         # a coder launch is a latency chain on a handful of CUs: the chunks' launches run side by side, each on a
         # stream of its own (on ONE stream they would queue up behind each other, ~50 ms apiece)
         side = _stream(dev, "coder%d" % (ci % CODER_STREAMS))
@@ -606,17 +640,95 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     ys, zs = [None] * B, [None] * B
     segments = []
     overflow = False
-    for i, (s0, n, keep, ypart, zpart, coded) in enumerate(queued):
-        overflow, host_t, offs = _drain(dev, copy, coded, [ypart, zpart])
-        if overflow:
-            break
+
+    def drain(i):
+        (s0, n, keep, ypart, zpart, coded) = queued[i]
+        over, host_t, offs = _drain(dev, copy, coded, [ypart, zpart])
+        if over:
+            return True
         queued[i] = None  # the chunk's records (20 B per symbol) and scratch go back to the allocator
-        del keep, ypart, zpart
         mv = memoryview(host_t.numpy())
         yo, zo = offs
-        ys[s0:s0 + n] = [bytes(mv[yo[i]:yo[i + 1]]) for i in range(n)]
-        zs[s0:s0 + n] = [bytes(mv[zo[i]:zo[i + 1]]) for i in range(n)]
+        ys[s0:s0 + n] = [bytes(mv[yo[k]:yo[k + 1]]) for k in range(n)]
+        zs[s0:s0 + n] = [bytes(mv[zo[k]:zo[k + 1]]) for k in range(n)]
         segments.append((s0, n, host_t, yo, zo))
+        return False
+
+    if host_trace is not None:
+        host_trace.append(("hyper-queued", n_host, time.perf_counter()))
+    for i in range(len(queued) - 1):
+        if drain(i):
+            overflow = True
+            break
+    if host_trace is not None:
+        host_trace.append(("hyper-drained", len(queued) - 1, time.perf_counter()))
+    if n_host and not overflow:
+        # the host's tiles: y symbols and their table rows, z symbols, [stream][position] int32 through page-locked buffers
+        hz = eb.coder_tables_host()
+        hy = gc.coder_tables_host()
+        zeros = torch.zeros(net.M, device=dev, dtype=torch.float32)
+        sub = max(1, 4 * ops.host_threads())
+        st_y = st_i = st_z = None
+
+        def host_encode(entry):
+            (t0, m, _keep, landed) = entry
+            w0 = time.perf_counter()
+            landed.synchronize()
+            w1 = time.perf_counter()
+            yout, ynb = ops.rans_encode_host(st_y[t0:t0 + m].numpy(), ny, 0, hy[0], hy[1], hy[2], hy[3], indexes=st_i[t0:t0 + m].numpy())
+            w2 = time.perf_counter()
+            _note_host_rate("enc", m, ny, w2 - w1, expect_ns=HYPER_HOST_CODER_NS["enc"])
+            zout, znb = ops.rans_encode_host(st_z[t0:t0 + m].numpy(), nz, zplane, hz[0], hz[1], hz[2], hz[3])
+            w3 = time.perf_counter()
+            ys[n_dev + t0:n_dev + t0 + m] = [yout[k, : int(ynb[k])].tobytes() for k in range(m)]
+            zs[n_dev + t0:n_dev + t0 + m] = [zout[k, : int(znb[k])].tobytes() for k in range(m)]
+            if host_trace is not None:
+                host_trace.append(("hyper-enc", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (w3 - w2), 3),
+                                   round(1e3 * (time.perf_counter() - w3), 3)))
+
+        pending = None
+        try:
+            for (t0, m) in _ramp(n_host, ops.host_threads(), sub):
+                y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
+                z = net.h_a(y)
+                if shape is None:
+                    shape = tuple(z.shape[-2:])
+                    ny, nz, zplane = y[0].numel(), z[0].numel(), z[0, 0].numel()
+                if st_y is None:
+                    st_y, st_i, st_z = _pinned_i32("hy", n_host, ny), _pinned_i32("hi", n_host, ny), _pinned_i32("hz", n_host, nz)
+                zsym = torch.empty((m, nz), device=dev, dtype=torch.int32)
+                ops.eb_quantize(z, med, "symbols", symbols=zsym, sym_stride_b=nz, sym_stride_i=1)
+                z_hat = ops.eb_quantize(z, med, "dequantize")
+                scales = net.h_s(z_hat)
+                ysym = torch.empty((m, ny), device=dev, dtype=torch.int32)
+                ops.eb_quantize(y.contiguous(), zeros, "symbols", symbols=ysym, sym_stride_b=ny, sym_stride_i=1)
+                yidx = torch.empty((m, ny), device=dev, dtype=torch.int32)
+                ops.gc_build_indexes(scales.contiguous(), gc.scale_table, bound, yidx, ny, 1)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(hcopy):
+                    hcopy.wait_event(ready)
+                    st_y[t0:t0 + m].copy_(ysym, non_blocking=True)
+                    st_i[t0:t0 + m].copy_(yidx, non_blocking=True)
+                    st_z[t0:t0 + m].copy_(zsym, non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record(hcopy)
+                entry = (t0, m, (ysym, yidx, zsym), landed)
+                del y, z, z_hat, scales
+                if pending is not None:
+                    host_encode(pending)
+                pending = entry
+            if pending is not None:
+                host_encode(pending)
+        except BaseException:
+            torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffers
+            raise
+    if host_trace is not None:
+        host_trace.append(("hyper-host-done", n_host, time.perf_counter()))
+    if queued and not overflow:
+        overflow = drain(len(queued) - 1)
+    if host_trace is not None:
+        host_trace.append(("hyper-last-drained", 0, time.perf_counter()))
     if overflow:
         torch.cuda.synchronize(dev)
         if cap_words is not None:
@@ -626,6 +738,7 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     for ci in range(min(CODER_STREAMS, len(segments))):
         main.wait_stream(_stream(dev, "coder%d" % ci))
     main.wait_stream(copy)
+    main.wait_stream(hcopy)
     ysegs = [(s0, n, t, yo) for (s0, n, t, yo, _) in segments]
     zsegs = [(s0, n, t, zo) for (s0, n, t, _, zo) in segments]
     return {"strings": [PackedStrings(ys, ysegs), PackedStrings(zs, zsegs)], "shape": torch.Size(shape)}
@@ -633,23 +746,33 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
 
 def _upload(strs, pieces, dev, id_base=0):
     """Per piece (s0, n): (device bytes, device int64 offsets [n+1]) of strs[s0:s0+n] - straight from compress()'s
-    page-locked segments when `strs` still is what compress() returned, else re-joined through a staging buffer."""
+    page-locked segment when `strs` still is what compress() returned and a segment starts at s0 and covers the piece,
+    else re-joined through a staging buffer (the tiles the host encoded have no segment)."""
     from .entropy_models import EntropyBottleneck
-    if isinstance(strs, PackedStrings) and strs.still_packed() and [(s, n) for (s, n, _, _) in strs.segments] == list(pieces):
-        out = []
-        for (_, n, host_t, off) in strs.segments:
+    segs = {}
+    if isinstance(strs, PackedStrings) and strs.still_packed():
+        segs = {s: (n, host_t, off) for (s, n, host_t, off) in strs.segments}
+    out = []
+    for k, (s0, n) in enumerate(pieces):
+        if s0 in segs and segs[s0][0] >= n:
+            _, host_t, off = segs[s0]
+            off = off[:n + 1]
             lo, hi = int(off[0]), int(off[-1])
             lo4 = lo & ~3
             data = host_t[lo4: max(hi, lo4 + 4)].to(dev, non_blocking=True)
             out.append((data, torch.from_numpy(off - lo4).to(dev, non_blocking=True)))
-        return out
-    return [EntropyBottleneck.pack_strings(strs[s0:s0 + n], dev, slot=(id_base + k)) for k, (s0, n) in enumerate(pieces)]
+        else:
+            out.append(EntropyBottleneck.pack_strings(strs[s0:s0 + n], dev, slot=(id_base + k)))
+    return out
 
 
 def decompress_hyper(net, strings, shape, chunk=512):
     """ScaleHyperprior.decompress for a large batch: every tile's z string is decoded in one launch, then per chunk
     h_s + the row-byte kernel run on the main stream and the chunk's y decoder on the side stream - ALL chunks' decoders
-    are in flight before the first synthesis transform starts, which then overlaps the later chunks' decoding."""
+    are in flight before the first synthesis transform starts, which then overlaps the later chunks' decoding.  The
+    call's last hyper_host_share(B, "dec") tiles are decoded by the host cores meanwhile (table rows [stream][position]
+    down, symbols up through page-locked buffers, sub-chunk k + 1's rows queued before k is decoded) and synthesised on
+    a stream of their own during the first device decoder launch, when the device has nothing else to do."""
     from . import engine
     eb, gc = net.entropy_bottleneck, net.gaussian_conditional
     zcdf, zlen, zoff, _ = eb.coder_tables()
@@ -669,14 +792,22 @@ def decompress_hyper(net, strings, shape, chunk=512):
     main = torch.cuda.current_stream(dev)
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
-    pieces = [(s0, n) for (s0, n) in _chunks(B, chunk)]
+    n_host = hyper_host_share(B, "dec")
+    n_dev = B - n_host
+    pieces = [(s0, n) for (s0, n) in _chunks(n_dev, chunk)]
     # PackedStrings carry compress()'s own chunking; decode in those pieces when it is intact
-    if isinstance(ystrs, PackedStrings) and ystrs.still_packed():
-        pieces = [(s0, n) for (s0, n, _, _) in ystrs.segments]
+    if isinstance(ystrs, PackedStrings) and ystrs.still_packed() and ystrs.segments:
+        pieces, covered = [], 0
+        for (s0, n, _, _) in ystrs.segments:
+            if s0 != covered or covered >= n_dev:
+                break
+            pieces.append((s0, min(n, n_dev - s0)))
+            covered = s0 + pieces[-1][1]
+        pieces += [(covered + t0, m) for (t0, m) in _chunks(n_dev - covered, chunk)]  # tiles the host encoded but the device decodes
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     zsym = torch.empty((nz, B), device=dev, dtype=torch.int32)
     # z: every tile's string in ONE launch (2 ms whatever the batch; a launch per piece would queue them up on this stream)
-    zup = _upload(zstrs, pieces, dev)
+    zup = _upload(zstrs, pieces + ([(n_dev, n_host)] if n_host else []), dev)
     if len(zup) > 1:  # (every string is a whole number of 32-bit words: the pieces concatenate without padding)
         zdata = torch.cat([data for (data, _) in zup])
         base, offs = 0, []
@@ -689,12 +820,54 @@ def decompress_hyper(net, strings, shape, chunk=512):
     _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
                                                            status=status, off_offset=0))
     z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
-    yup = _upload(ystrs, pieces, dev, id_base=len(pieces))  # staging slots behind the z pieces': no slot is shared in a call
+    yup = _upload(ystrs, pieces, dev, id_base=len(pieces) + 1)  # staging slots behind the z pieces': no slot is shared in a call
     fp16 = net.precision == "fp16"
     st = engine.stages(net.g_s)
     cout = st[-1][0].out_channels
     x_hat = torch.empty((B, cout, 64 * h, 64 * w), device=dev, dtype=torch.float32)
     zeros = torch.zeros(M, device=dev, dtype=torch.float32)
+
+    def synthesise(s0, n, sym, stride_b, stride_i):
+        if fp16:
+            y_blk = torch.empty((n, M // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16) if M % 16 == 0 else \
+                torch.zeros((n, (M + 15) // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16)
+            ops.eb_dequantize(sym, stride_b, stride_i, zeros, n, M, 4 * h, 4 * w, want_nchw=False, blk16=y_blk)
+            engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+        else:
+            y_hat = ops.eb_dequantize(sym, stride_b, stride_i, zeros, n, M, 4 * h, 4 * w)
+            x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
+
+    # the host's tiles: their table rows come down sub-chunk by sub-chunk (h_s and the row kernel on the stream `hsyn`)
+    hsyn = _stream(dev, "hostsyn")
+    hcopy = _stream(dev, "hostsym")
+    st_i = st_s = None
+    if n_host:
+        st_i, st_s = _pinned_i32("hi", n_host, ny), _pinned_i32("hy", n_host, ny)
+        zready = torch.cuda.Event()
+        zready.record(main)
+        hsyn.wait_event(zready)
+
+    def host_rows(t0, m):
+        with torch.cuda.stream(hsyn):
+            scales = net.h_s(z_hat[n_dev + t0:n_dev + t0 + m])
+            yidx = torch.empty((m, ny), device=dev, dtype=torch.int32)
+            ops.gc_build_indexes(scales.contiguous(), gc.scale_table, bound, yidx, ny, 1)
+            ready = torch.cuda.Event()
+            ready.record(hsyn)
+        with torch.cuda.stream(hcopy):
+            hcopy.wait_event(ready)
+            st_i[t0:t0 + m].copy_(yidx, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(hcopy)
+        return (t0, m, yidx, landed)
+
+    subs = list(_ramp(n_host, ops.host_threads(), max(1, 4 * ops.host_threads()))) if n_host else []
+    pending = None
+    if subs:
+        pending = host_rows(*subs[0])
+        packed_ev = torch.cuda.Event()  # (the first h_s call packs the weights: the main stream's own follows it)
+        packed_ev.record(hsyn)
+        main.wait_event(packed_ev)
     events, keep = [], []
     for ci, ((s0, n), (data, off)) in enumerate(zip(pieces, yup)):
         side = _stream(dev, "coder%d" % (ci % CODER_STREAMS))
@@ -711,16 +884,52 @@ def decompress_hyper(net, strings, shape, chunk=512):
         events.append(ev)
         keep.append((data, off, idx16, sym))
         del scales
-    for (s0, n), ev, (_, _, _, sym) in zip(pieces, events, keep):
-        main.wait_event(ev)
-        if fp16:
-            y_blk = torch.empty((n, M // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16) if M % 16 == 0 else \
-                torch.zeros((n, (M + 15) // 16, 4 * h, 4 * w, 16), device=dev, dtype=torch.float16)
-            ops.eb_dequantize(sym, 1, n, zeros, n, M, 4 * h, 4 * w, want_nchw=False, blk16=y_blk)
-            engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
-        else:
-            y_hat = ops.eb_dequantize(sym, 1, n, zeros, n, M, 4 * h, 4 * w)
-            x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
-    if int(status.item()) != 0:  # synchronises; also keeps the side stream's tensors alive until it is done
+
+    def synthesise_device_pieces():
+        for (s0, n), ev, (_, _, _, sym) in zip(pieces, events, keep):
+            main.wait_event(ev)
+            synthesise(s0, n, sym, 1, n)
+
+    if subs:
+        hy = gc.coder_tables_host()
+        queued_device = False
+        for k in range(len(subs)):
+            (t0, m, _yidx, landed) = pending
+            pending = host_rows(*subs[k + 1]) if k + 1 < len(subs) else None
+            w0 = time.perf_counter()
+            part = ystrs[n_dev + t0:n_dev + t0 + m]
+            lens = np.fromiter((len(b_) for b_ in part), dtype=np.int64, count=m)
+            byte_off = np.zeros(m + 1, dtype=np.int64)
+            np.cumsum(lens, out=byte_off[1:])
+            joined = np.frombuffer(b"".join(part), dtype=np.uint8)
+            landed.synchronize()
+            w1 = time.perf_counter()
+            try:
+                _, bad = ops.rans_decode_host(joined, byte_off, ny, 0, hy[0], hy[1], hy[2], m, indexes=st_i[t0:t0 + m].numpy(),
+                                              out=st_s[t0:t0 + m].numpy())
+            except BaseException:
+                torch.cuda.synchronize(dev)  # earlier sub-chunks' uploads still read the shared page-locked buffer
+                raise
+            w2 = time.perf_counter()
+            _note_host_rate("dec", m, ny, w2 - w1, expect_ns=HYPER_HOST_CODER_NS["dec"])
+            if bad != 0:
+                torch.cuda.synchronize(dev)
+                raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+            with torch.cuda.stream(hsyn):
+                hsym = st_s[t0:t0 + m].to(dev, non_blocking=True)
+                synthesise(n_dev + t0, m, hsym, ny, 1)
+            keep.append((hsym, _yidx))
+            if host_trace is not None:
+                host_trace.append(("hyper-dec", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
+            if not queued_device:  # (the first g_s call packed the weights)
+                packed_ev = torch.cuda.Event()
+                packed_ev.record(hsyn)
+                main.wait_event(packed_ev)
+                synthesise_device_pieces()
+                queued_device = True
+        main.wait_stream(hsyn)
+    else:
+        synthesise_device_pieces()
+    if int(status.item()) != 0:  # synchronises; also keeps the side streams' tensors alive until they are done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
     return {"x_hat": x_hat}

@@ -134,3 +134,41 @@ def test_every_zoo_model_and_width_round_trips(model, quality):
             dec = net.decompress(comp["strings"], comp["shape"])["x_hat"]
         assert bool(torch.isfinite(out["x_hat"]).all())
         assert float((dec - out["x_hat"].clamp(0, 1)).abs().max()) < (1e-5 if prec == "fp32" else 1e-6), (model, quality, prec)
+
+
+def test_hyper_codec_host_share_changes_nothing(monkeypatch):
+    """compress_hyper / decompress_hyper with the call's last tiles coded by the host cores (codec.hyper_host_share: y
+    symbols and table rows, z symbols over PCIe, the host coder with explicit per-symbol rows): the same y and z strings
+    as the all-device call, and decompress - whatever it decodes where, also when its host share is not the encoder's -
+    returns the same tiles."""
+    from licos_amd import codec, ops
+    monkeypatch.setattr(ops, "HOST_CODER", "0")  # the large-batch pipeline whatever the batch
+    torch.manual_seed(11)
+    net = licos_amd.get_model("bmshj2018-hyperprior", False, 3, 1).to(DEV).eval().set_precision("fp16")
+    with torch.no_grad():
+        licos_amd.synthetic.make_trained_like(net, seed=3)
+    net.update(force=True)
+    net.chunk = 8 * 16  # _chunk_for scales by the tile area: 8 tiles of 128^2 per pipeline chunk
+    x = licos_amd.synthetic.tiles(21, 3, 128, seed=9, device=DEV)
+    share = {"enc": 0, "dec": 0}
+    monkeypatch.setattr(codec, "hyper_host_share", lambda batch, direction="enc": share[direction])
+    with torch.no_grad():
+        c0 = net.compress(x)
+        ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
+        ys0, zs0 = [bytes(s_) for s_ in c0["strings"][0]], [bytes(s_) for s_ in c0["strings"][1]]
+        monkeypatch.setattr(ops, "host_threads", lambda: 2)
+        for enc, dec in ((5, 5), (9, 3), (3, 9), (0, 6), (6, 0), (7, 7)):
+            share["enc"], share["dec"] = enc, dec
+            c = net.compress(x)
+            assert [bytes(s_) for s_ in c["strings"][0]] == ys0 and [bytes(s_) for s_ in c["strings"][1]] == zs0, (enc, dec)
+            assert sum(n for _, n, _, _ in c["strings"][0].segments) == 21 - enc
+            assert torch.equal(net.decompress(c["strings"], c["shape"])["x_hat"], ref), (enc, dec)
+            plain = [[bytes(s_) for s_ in lst] for lst in c["strings"]]
+            assert torch.equal(net.decompress(plain, c["shape"])["x_hat"], ref), (enc, dec)
+        # a truncated y string among the host's tiles is reported like one among the device's
+        share["enc"], share["dec"] = 0, 6
+        bad = [[bytes(s_) for s_ in lst] for lst in c0["strings"]]
+        bad[0][19] = bad[0][19][:8]
+        with pytest.raises(ValueError):
+            net.decompress(bad, c0["shape"])
+        torch.cuda.synchronize()

@@ -450,3 +450,31 @@ def test_host_capacity_follows_the_measured_host_rate(monkeypatch):
     for _ in range(10):
         codec._note_host_rate("enc", 256, nsym, 256 * nsym * 1.8e-9 / 16)
     assert codec.host_capacity("enc") >= 0.99 * cap0
+
+
+def test_hyper_host_share_policy(monkeypatch):
+    """codec.hyper_host_share (scale hyperprior, large calls): what the host threads code during one exposed device coder
+    launch, in steps of 4 x threads, at most a third of the call, nothing when the host coder or the split is off; it
+    moves only when the measured host rate has moved it by a whole step."""
+    from licos_amd import codec, ops
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    monkeypatch.setattr(ops, "host_threads", lambda: 16)
+    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    monkeypatch.setattr(codec, "_host_factor", {"enc": 1.0, "dec": 1.0})
+    monkeypatch.setattr(codec, "_hyper_share", {})
+    monkeypatch.delenv("LICOS_HYPER_SHARE", raising=False)
+    for d in ("enc", "dec"):
+        cap = 0.85 * 16 * codec.HYPER_DEV_NS[d] / codec.HYPER_HOST_NS[d]
+        want = int(cap) // 64 * 64
+        assert want >= 128
+        assert codec.hyper_host_share(4096, d) == want == codec.hyper_host_share(2048, d)
+        assert codec.hyper_host_share(600, d) == 192 and codec.hyper_host_share(400, d) == 128  # a third of the call at most
+        codec._host_factor[d] = cap / (want - 40.0)   # the host a little slower: under a step, the share stays
+        assert codec.hyper_host_share(4096, d) == want
+        codec._host_factor[d] = 2.0                    # half the rate: half the share (on the grid)
+        assert codec.hyper_host_share(4096, d) == int(cap / 2) // 64 * 64
+    monkeypatch.setattr(codec, "HOST_SPLIT", False)
+    assert codec.hyper_host_share(4096) == 0
+    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    monkeypatch.setattr(ops, "HOST_CODER", "0")
+    assert codec.hyper_host_share(4096, "dec") == 0

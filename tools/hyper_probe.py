@@ -24,10 +24,15 @@ else:
 net.chunk = chunk
 x = synthetic.tiles(B, 13, 512, seed=300, kind="s2-merged", device=dev)
 with torch.no_grad():
-    for it in range(3):
-        if it == 2:
+    iters = int(os.environ.get("PROBE_ITERS", "3"))
+    for it in range(iters):
+        if it >= 2:
+            if it > 2:
+                print("   coder ms:", {k: ["%.1f" % e0.elapsed_time(e1) for e0, e1 in v] for k, v in codec.coder_events.items()},
+                      "stages %.1f ms" % sum(e0.elapsed_time(e1) for v in engine.stage_events.values() for e0, e1 in v))
             codec.coder_events, engine.stage_events = {}, {}
         torch.cuda.synchronize()
+        codec.host_trace = [] if "--trace" in sys.argv else None
         t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize()
@@ -35,6 +40,11 @@ with torch.no_grad():
         d = net.decompress(c["strings"], c["shape"])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        if codec.host_trace is not None:
+            tr, codec.host_trace = codec.host_trace, None
+            print("  enc factor %.2f" % codec._host_factor["enc"])
+            for e in tr:
+                print("  ", e[:2], ["%.1f" % (1e3 * (v - t0)) if e[0] not in ("hyper-enc", "hyper-dec") else v for v in e[2:]])
         print("iter %d: compress %.1f ms, decompress %.1f ms, %.0f tiles/s" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), B / (t2 - t0)), flush=True)
 nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
 for k, evs in codec.coder_events.items():

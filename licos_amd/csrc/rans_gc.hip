@@ -47,9 +47,13 @@ __device__ inline int scale_row(float s, const float *__restrict__ table, int le
 }
 
 // block = 64 streams x 32 positions; latents and scales are read along positions (NCHW rows), records leave along
-// streams (the coder's lanes), through LDS
+// streams (the coder's lanes), through LDS.
 // BY_SCALE: the row of an element is chosen by its predicted scale (GaussianConditional); otherwise it is the element's
 // channel, position / plane, and the symbol is round(y - median[channel]) (EntropyBottleneck: `scales` = the medians).
+// A thread owns 4 consecutive positions of 2 streams.  Its 8 elements go through the kernel's three dependent memory
+// steps TOGETHER - all latents and scales (16-byte loads when n % 4 == 0), then all row lengths / offsets, then all 8
+// table records - so a workgroup pays three round trips, not the 24 of an element-at-a-time loop (round 4: 6.9 -> see
+// DESIGN 6.1 per 2048 tiles of 196 608 symbols; the launch sits on the main stream in front of every chunk's coder).
 template <bool BY_SCALE>
 __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__restrict__ y, const float *__restrict__ scales,
                                                                const float *__restrict__ table, int levels, float bound,
@@ -62,29 +66,103 @@ __global__ __launch_bounds__(256) void gc_encode_prepare_kernel(const float *__r
   const long i0 = (long)blockIdx.x * 32;
   const int b0 = blockIdx.y * 64;
   {
-    const int p = threadIdx.x & 31;
-    const long i = i0 + p;
-    for (int r = threadIdx.x >> 5; r < 64; r += 8) {
-      const int b = b0 + r;
-      uint4 e = make_uint4(0, 0, 0, 0);
-      int32_t raw = 0;
-      if (i < n && b < B) {
-        const size_t at = (size_t)b * n + i;
-        const int c = BY_SCALE ? scale_row(scales[at], table, levels, bound) : (int)(i / levels);  // (`levels` = the plane size)
-        const int32_t max_value = cdf_len[c] - 2;
-        const float centred = BY_SCALE ? y[at] : y[at] - scales[c];
-        int32_t v = (int32_t)rintf(centred) - offset[c];  // round-half-to-even, as torch.round
-        bool esc = false;
-        if (v < 0) { raw = -2 * v - 1; v = max_value; esc = true; }
-        else if (v >= max_value) { raw = 2 * (v - max_value); v = max_value; esc = true; }
-        e = enc_table[(size_t)c * cdf_stride + v];
+    const int q = threadIdx.x & 7, r0 = threadIdx.x >> 3;  // positions 4q .. 4q + 3 of streams r0 and r0 + 32
+    const long i = i0 + 4 * q;
+    // (n % 4 == 0 and 16-byte aligned planes: every stream starts on a 16-byte boundary, and i + 3 < n whenever i < n)
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | (BY_SCALE ? reinterpret_cast<uintptr_t>(scales) : 0)) & 15) == 0;
+    float yv[2][4], sv[2][4];
+    bool live[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = b0 + r0 + 32 * h;
+      const size_t at = (size_t)b * n + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        live[h][j] = b < B && i + j < n;
+        yv[h][j] = 0.f;
+        sv[h][j] = 0.f;
+      }
+      if (vec) {
+        if (live[h][0]) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(y + at);
+          yv[h][0] = a4.x; yv[h][1] = a4.y; yv[h][2] = a4.z; yv[h][3] = a4.w;
+          if (BY_SCALE) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(scales + at);
+            sv[h][0] = s4.x; sv[h][1] = s4.y; sv[h][2] = s4.z; sv[h][3] = s4.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (live[h][j]) {
+            yv[h][j] = y[at + j];
+            if (BY_SCALE) sv[h][j] = scales[at + j];
+          }
+      }
+    }
+    int c[2][4];
+    if (BY_SCALE) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sv[h][j] = fmaxf(sv[h][j], bound);
+          c[h][j] = levels - 1;
+        }
+      for (int t = 0; t < levels - 1; ++t) {  // (scale_row for the 8 elements at once: one table value per step)
+        const float tv = table[t];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[h][j] -= (sv[h][j] <= tv) ? 1 : 0;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[h][j] = live[h][j] ? (int)((i + j) / levels) : 0;  // (`levels` = the plane size)
+    }
+    int32_t maxv[2][4], offs[2][4];
+    float med[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        maxv[h][j] = cdf_len[c[h][j]] - 2;
+        offs[h][j] = offset[c[h][j]];
+        med[h][j] = BY_SCALE ? 0.f : scales[c[h][j]];
+      }
+    int32_t v[2][4], raw[2][4];
+    bool esc[2][4];
+    uint4 e[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float centred = BY_SCALE ? yv[h][j] : yv[h][j] - med[h][j];
+        int32_t vv = (int32_t)rintf(centred) - offs[h][j];  // round-half-to-even, as torch.round
+        int32_t rr = 0;
+        bool ee = false;
+        if (vv < 0) { rr = -2 * vv - 1; vv = maxv[h][j]; ee = true; }
+        else if (vv >= maxv[h][j]) { rr = 2 * (vv - maxv[h][j]); vv = maxv[h][j]; ee = true; }
+        v[h][j] = vv; raw[h][j] = rr; esc[h][j] = ee;
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[h][j] = enc_table[(size_t)c[h][j] * cdf_stride + v[h][j]];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4 ev = e[h][j];
         // the serial kernel's form of the last dword: 2^16 - freq (what the update multiplies by, and what the
         // renormalisation bound is computed from) | shift << 16 | escape flag
-        e.w = ((0x10000u - (e.w & 0xFFFFu)) & 0xFFFFu) | (e.w & 0x7FFF0000u) | (esc ? REC_ESCAPE : 0u);
+        ev.w = ((0x10000u - (ev.w & 0xFFFFu)) & 0xFFFFu) | (ev.w & 0x7FFF0000u) | (esc[h][j] ? REC_ESCAPE : 0u);
+        if (!live[h][j]) { ev = make_uint4(0, 0, 0, 0); raw[h][j] = 0; }
+        t_rec[4 * q + j][r0 + 32 * h] = ev;
+        t_aux[4 * q + j][r0 + 32 * h] = raw[h][j];
       }
-      t_rec[p][r] = e;
-      t_aux[p][r] = raw;
-    }
   }
   __syncthreads();
   {
@@ -263,16 +341,58 @@ __global__ __launch_bounds__(256) void gc_decode_prepare_kernel(const float *__r
   const long i0 = (long)blockIdx.x * 64;
   const int b0 = blockIdx.y * 64;
   {
-    const int p = threadIdx.x & 63;
-    const long i = i0 + p;
-    for (int r = threadIdx.x >> 6; r < 64; r += 4) {
-      const int b = b0 + r;
-      int c = 0;
-      if (i < n && b < B) {
-        c = scale_row(scales[(size_t)b * n + i], table, levels, bound);
-        if (row_hist && ((p ^ r) & 7) == 0) atomicAdd(&s_hist[c], 1u);  // a 1-in-8 sample of the rows in use
+    // a thread owns 4 consecutive positions of 4 streams; the 16 scales are loaded before the first is looked at
+    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    const long i = i0 + 4 * q;
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(scales) & 15) == 0;
+    float sv[4][4];
+    bool live[4][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int b = b0 + r0 + 16 * h;
+      const size_t at = (size_t)b * n + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        live[h][j] = b < B && i + j < n;
+        sv[h][j] = 0.f;
       }
-      tile[r][p] = (uint8_t)c;
+      if (vec) {
+        if (live[h][0]) {
+          const float4 s4 = *reinterpret_cast<const float4 *>(scales + at);
+          sv[h][0] = s4.x; sv[h][1] = s4.y; sv[h][2] = s4.z; sv[h][3] = s4.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (live[h][j]) sv[h][j] = scales[at + j];
+      }
+    }
+    int c[4][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sv[h][j] = fmaxf(sv[h][j], bound);
+        c[h][j] = levels - 1;
+      }
+    for (int t = 0; t < levels - 1; ++t) {
+      const float tv = table[t];
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[h][j] -= (sv[h][j] <= tv) ? 1 : 0;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int r = r0 + 16 * h;
+      uint32_t packed = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = live[h][j] ? c[h][j] : 0;
+        if (row_hist && live[h][j] && (((4 * q + j) ^ r) & 7) == 0) atomicAdd(&s_hist[cc], 1u);  // a 1-in-8 sample of the rows in use
+        packed |= (uint32_t)cc << (8 * j);
+      }
+      *reinterpret_cast<uint32_t *>(&tile[r][4 * q]) = packed;
     }
   }
   __syncthreads();

@@ -191,6 +191,15 @@ int licos_gc_likelihood(const float *v, const float *scales, float *lik, float s
  * coder's addressing (element (b, i) at b*stride_b + i*stride_i, i = c*HW + p). */
 int licos_gc_build_indexes(const float *scales, const float *table, int levels, float scale_bound, int32_t *indexes,
                            long stride_b, long stride_i, int B, long n, void *stream);
+/* What the host coder (licos_rans_*_host_packed / _rows8 below) needs of a y stream, in as few bytes as PCIe allows, when
+ * the host cores code part of a scale-hyperprior call beside the device (GaussianConditional.compress / decompress,
+ * [CAI] entropy_models.py: indexes = build_indexes(scales), symbols = round(y)).  Plain [stream][position] layout.
+ * pack: packed[b*n + i] = row << 16 | (round(y) & 0xFFFF); flag[0] |= 1 if a symbol does not fit int16 (the caller must
+ *       then use the int32 form).  rows8: one table-row byte per symbol (levels <= 256). */
+int licos_gc_pack_symbols(const float *y, const float *scales, const float *table, int levels, float scale_bound, int32_t *packed,
+                          int32_t *flag, int B, long n, void *stream);
+int licos_gc_build_rows8(const float *scales, const float *table, int levels, float scale_bound, uint8_t *rows8, int B, long n,
+                         void *stream);
 
 /* Sentinel-2 raw DN -> model input grid (the step before the path):
  * /root/reference/licos/raw_image_folder.py:192-196 with use_full_range=False: x = DN / 4095 (raw_utils.py:128),
@@ -262,6 +271,15 @@ int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long 
 int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const int32_t *indexes, long sym_stride_b,
                            long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
                            const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int B, int nthreads);
+/* The host coder on the compact forms licos_gc_pack_symbols / licos_gc_build_rows8 produce (explicit per-symbol rows):
+ * encode from packed words [B][n] (stream b at packed + b*stride_b); decode with row bytes [B][n] into int32 symbols
+ * [B][n] (both at b*stride_b).  Same streams, same errors as the two functions above. */
+int licos_rans_encode_host_packed(const int32_t *packed, long stride_b, int n, const int32_t *cdf, int cdf_stride,
+                                  const int32_t *cdf_len, const int32_t *offset, int rows, const void *enc_table, uint8_t *out,
+                                  long cap_bytes_per_stream, int64_t *nbytes, int B, int nthreads);
+int licos_rans_decode_host_rows8(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const uint8_t *rows8, long stride_b, int n,
+                                 const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int rows,
+                                 int32_t *symbols, int32_t *status, int B, int nthreads);
 /* gathers each stream's words (in stream order) into one packed little-endian
  * byte buffer: stream b occupies out[byte_off[b] .. byte_off[b] + 4*nwords[b]).
  * byte_off[B] = exclusive prefix sum of 4*nwords (computed by the caller). */

@@ -558,9 +558,9 @@ def hyper_retry_chunk(chunk, ny):
     return max(1, min(chunk, ((1 << 32) - 1) // (4 * (cap + 1))))
 
 
-HYPER_HOST_NS = {"enc": float(os.environ.get("LICOS_HYPER_HOST_ENC_NS", "4.2")),   # host coder with explicit per-symbol rows, ns per symbol
-                 "dec": float(os.environ.get("LICOS_HYPER_HOST_DEC_NS", "6.0"))}   # and thread (y + z streams, string handling included)
-HYPER_HOST_CODER_NS = {"enc": 3.6, "dec": 5.2}                                      # the y coder call alone (what _note_host_rate sees)
+HYPER_HOST_NS = {"enc": float(os.environ.get("LICOS_HYPER_HOST_ENC_NS", "3.5")),   # host coder with explicit per-symbol rows, ns per symbol
+                 "dec": float(os.environ.get("LICOS_HYPER_HOST_DEC_NS", "4.9"))}   # and thread (what balanced the two sides on the box)
+HYPER_HOST_CODER_NS = {"enc": 3.7, "dec": 5.0}                                      # the y coder call alone (what _note_host_rate sees)
 HYPER_DEV_NS = {"enc": 159.0, "dec": 117.0}                                         # the device y coders' latency per symbol
 _hyper_share = {}
 
@@ -587,14 +587,19 @@ def hyper_host_share(batch, direction="enc"):
     return max(0, min(last, batch // 3 // step * step))
 
 
-def compress_hyper(net, x, chunk=512, cap_words=None):
+class _HostRange(Exception):
+    """A y symbol of a host tile does not fit the 16 bits of the packed word (ops.gc_pack_symbols)."""
+
+
+def compress_hyper(net, x, chunk=512, cap_words=None, host=True):
     """ScaleHyperprior.compress ([CAI] models/google.py) for a large batch, either precision: per chunk the four
     transforms run on the main stream, then ONE throughput kernel turns (y, scales) into per-symbol encoder records
     (licos_gc_encode_prepare) and the two serial coder kernels (z: plane coder, y: record coder) run on the side stream
     under the next chunk's transforms.  z_hat is round(z - median) + median computed directly: the reference obtains it
     by decoding the z string it has just written, which returns exactly those integers.  The call's last
-    hyper_host_share(B) tiles are coded by the host cores (symbols and table rows [stream][position] over PCIe, sub-chunk
-    k queued before k - 1 is coded) while the last device launch runs."""
+    hyper_host_share(B) tiles are coded by the host cores (one word per y symbol - table row << 16 | symbol - and the z
+    symbols, [stream][position] over PCIe, sub-chunk k queued before k - 1 is coded) while the last device launch runs;
+    a y symbol outside 16 bits sends the whole call to the device (`host=False`)."""
     eb, gc = net.entropy_bottleneck, net.gaussian_conditional
     zcdf, zlen, zoff, ztab = eb.coder_tables()
     ycdf, ylen, yoff, ytab = gc.coder_tables()
@@ -608,7 +613,7 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
     hcopy = _stream(dev, "hostsym")
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
-    n_host = hyper_host_share(B) if cap_words is None else 0
+    n_host = hyper_host_share(B) if (cap_words is None and host) else 0
     n_dev = B - n_host
     queued, shape = [], None
     for ci, (s0, n) in enumerate(_chunks(n_dev, chunk)):
@@ -666,16 +671,20 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
         # the host's tiles: y symbols and their table rows, z symbols, [stream][position] int32 through page-locked buffers
         hz = eb.coder_tables_host()
         hy = gc.coder_tables_host()
-        zeros = torch.zeros(net.M, device=dev, dtype=torch.float32)
         sub = max(1, 4 * ops.host_threads())
-        st_y = st_i = st_z = None
+        subs = list(_ramp(n_host, ops.host_threads(), sub))
+        hflag = torch.zeros(len(subs), device=dev, dtype=torch.int32)
+        st_y = st_z = None
+        st_f = _pinned_i32("hf", 1, max(64, len(subs)))[0]
 
         def host_encode(entry):
-            (t0, m, _keep, landed) = entry
+            (k, t0, m, _keep, landed) = entry
             w0 = time.perf_counter()
             landed.synchronize()
+            if int(st_f[k]) != 0:
+                raise _HostRange()
             w1 = time.perf_counter()
-            yout, ynb = ops.rans_encode_host(st_y[t0:t0 + m].numpy(), ny, 0, hy[0], hy[1], hy[2], hy[3], indexes=st_i[t0:t0 + m].numpy())
+            yout, ynb = ops.rans_encode_host_packed(st_y[t0:t0 + m].numpy(), ny, hy[0], hy[1], hy[2], hy[3])
             w2 = time.perf_counter()
             _note_host_rate("enc", m, ny, w2 - w1, expect_ns=HYPER_HOST_CODER_NS["enc"])
             zout, znb = ops.rans_encode_host(st_z[t0:t0 + m].numpy(), nz, zplane, hz[0], hz[1], hz[2], hz[3])
@@ -688,38 +697,40 @@ def compress_hyper(net, x, chunk=512, cap_words=None):
 
         pending = None
         try:
-            for (t0, m) in _ramp(n_host, ops.host_threads(), sub):
+            for k, (t0, m) in enumerate(subs):
                 y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
                 z = net.h_a(y)
                 if shape is None:
                     shape = tuple(z.shape[-2:])
                     ny, nz, zplane = y[0].numel(), z[0].numel(), z[0, 0].numel()
                 if st_y is None:
-                    st_y, st_i, st_z = _pinned_i32("hy", n_host, ny), _pinned_i32("hi", n_host, ny), _pinned_i32("hz", n_host, nz)
+                    st_y, st_z = _pinned_i32("hy", n_host, ny), _pinned_i32("hz", n_host, nz)
                 zsym = torch.empty((m, nz), device=dev, dtype=torch.int32)
                 ops.eb_quantize(z, med, "symbols", symbols=zsym, sym_stride_b=nz, sym_stride_i=1)
                 z_hat = ops.eb_quantize(z, med, "dequantize")
                 scales = net.h_s(z_hat)
-                ysym = torch.empty((m, ny), device=dev, dtype=torch.int32)
-                ops.eb_quantize(y.contiguous(), zeros, "symbols", symbols=ysym, sym_stride_b=ny, sym_stride_i=1)
-                yidx = torch.empty((m, ny), device=dev, dtype=torch.int32)
-                ops.gc_build_indexes(scales.contiguous(), gc.scale_table, bound, yidx, ny, 1)
+                ypk = torch.empty((m, ny), device=dev, dtype=torch.int32)
+                ops.gc_pack_symbols(y.contiguous(), scales.contiguous(), gc.scale_table, bound, ypk, hflag[k:k + 1])
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(hcopy):
                     hcopy.wait_event(ready)
-                    st_y[t0:t0 + m].copy_(ysym, non_blocking=True)
-                    st_i[t0:t0 + m].copy_(yidx, non_blocking=True)
+                    st_y[t0:t0 + m].copy_(ypk, non_blocking=True)
                     st_z[t0:t0 + m].copy_(zsym, non_blocking=True)
+                    st_f[k:k + 1].copy_(hflag[k:k + 1], non_blocking=True)
                     landed = torch.cuda.Event()
                     landed.record(hcopy)
-                entry = (t0, m, (ysym, yidx, zsym), landed)
+                entry = (k, t0, m, (ypk, zsym), landed)
                 del y, z, z_hat, scales
                 if pending is not None:
                     host_encode(pending)
                 pending = entry
             if pending is not None:
                 host_encode(pending)
+        except _HostRange:
+            torch.cuda.synchronize(dev)
+            del queued
+            return compress_hyper(net, x, chunk=chunk, host=False)
         except BaseException:
             torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffers
             raise
@@ -792,7 +803,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
     main = torch.cuda.current_stream(dev)
     med = eb.medians_vec()
     bound = gc.lower_bound_scale.bound_value
-    n_host = hyper_host_share(B, "dec")
+    n_host = hyper_host_share(B, "dec") if gc.scale_table.numel() <= 256 else 0  # (the host's rows travel as bytes)
     n_dev = B - n_host
     pieces = [(s0, n) for (s0, n) in _chunks(n_dev, chunk)]
     # PackedStrings carry compress()'s own chunking; decode in those pieces when it is intact
@@ -842,7 +853,7 @@ def decompress_hyper(net, strings, shape, chunk=512):
     hcopy = _stream(dev, "hostsym")
     st_i = st_s = None
     if n_host:
-        st_i, st_s = _pinned_i32("hi", n_host, ny), _pinned_i32("hy", n_host, ny)
+        st_i, st_s = _pinned_i32("hr", n_host, ny // 4).view(torch.uint8), _pinned_i32("hy", n_host, ny)  # (M % 4 == 0: ny too)
         zready = torch.cuda.Event()
         zready.record(main)
         hsyn.wait_event(zready)
@@ -850,8 +861,8 @@ def decompress_hyper(net, strings, shape, chunk=512):
     def host_rows(t0, m):
         with torch.cuda.stream(hsyn):
             scales = net.h_s(z_hat[n_dev + t0:n_dev + t0 + m])
-            yidx = torch.empty((m, ny), device=dev, dtype=torch.int32)
-            ops.gc_build_indexes(scales.contiguous(), gc.scale_table, bound, yidx, ny, 1)
+            yidx = torch.empty((m, ny), device=dev, dtype=torch.uint8)
+            ops.gc_build_rows8(scales.contiguous(), gc.scale_table, bound, yidx)
             ready = torch.cuda.Event()
             ready.record(hsyn)
         with torch.cuda.stream(hcopy):
@@ -905,8 +916,8 @@ def decompress_hyper(net, strings, shape, chunk=512):
             landed.synchronize()
             w1 = time.perf_counter()
             try:
-                _, bad = ops.rans_decode_host(joined, byte_off, ny, 0, hy[0], hy[1], hy[2], m, indexes=st_i[t0:t0 + m].numpy(),
-                                              out=st_s[t0:t0 + m].numpy())
+                bad = ops.rans_decode_host_rows8(joined, byte_off, st_i[t0:t0 + m].numpy(), ny, hy[0], hy[1], hy[2], m,
+                                                 out=st_s[t0:t0 + m].numpy())
             except BaseException:
                 torch.cuda.synchronize(dev)  # earlier sub-chunks' uploads still read the shared page-locked buffer
                 raise

@@ -419,6 +419,66 @@ __global__ void gc_build_indexes_kernel(const float *__restrict__ scales, const 
   }
 }
 
+// What the HOST coder needs of a tile's y stream, in as few bytes as PCIe allows (the host share of a scale-hyperprior
+// call, codec.compress_hyper / decompress_hyper): one word per symbol, table row << 16 | (round(y) & 0xFFFF), for the
+// encoder (`flag` is raised when a symbol does not fit 16 bits: the caller then codes the call on the device); one row
+// byte per symbol for the decoder.  Plain [stream][position] layout; 4 elements per thread, 16-byte loads when the
+// planes allow.
+template <bool PACK>
+__global__ __launch_bounds__(256) void gc_host_words_kernel(const float *__restrict__ y, const float *__restrict__ scales,
+                                                           const float *__restrict__ table, int levels, float scale_bound,
+                                                           int32_t *__restrict__ packed, uint8_t *__restrict__ rows8,
+                                                           int32_t *__restrict__ flag, long total) {
+  const bool vec = (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(scales) | (PACK ? reinterpret_cast<uintptr_t>(y) : 0)) & 15) == 0;
+  bool over = false;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long)gridDim.x * blockDim.x * 4) {
+    float sv[4], yv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int m = total - e < 4 ? (int)(total - e) : 4;
+    if (vec) {
+      const float4 s4 = *reinterpret_cast<const float4 *>(scales + e);
+      sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
+      if (PACK) {
+        const float4 y4 = *reinterpret_cast<const float4 *>(y + e);
+        yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sv[j] = j < m ? scales[e + j] : 0.f;
+        if (PACK) yv[j] = j < m ? y[e + j] : 0.f;
+      }
+    }
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sv[j] = fmaxf(sv[j], scale_bound);
+      c[j] = levels - 1;
+    }
+    for (int t = 0; t < levels - 1; ++t) {
+      const float tv = table[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] -= (sv[j] <= tv) ? 1 : 0;
+    }
+    if (PACK) {
+      int32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r = rintf(yv[j]);  // round-half-to-even, as torch.round
+        over = over || !(r >= -32768.f && r <= 32767.f);
+        w[j] = (int32_t)(((uint32_t)c[j] << 16) | ((uint32_t)(int32_t)fminf(fmaxf(r, -32768.f), 32767.f) & 0xFFFFu));
+      }
+      if (vec) *reinterpret_cast<int4 *>(packed + e) = make_int4(w[0], w[1], w[2], w[3]);
+      else
+        for (int j = 0; j < m; ++j) packed[e + j] = w[j];
+    } else {
+      if (vec) *reinterpret_cast<uchar4 *>(rows8 + e) = make_uchar4((uint8_t)c[0], (uint8_t)c[1], (uint8_t)c[2], (uint8_t)c[3]);
+      else
+        for (int j = 0; j < m; ++j) rows8[e + j] = (uint8_t)c[j];
+    }
+  }
+  if (PACK && over) atomicOr(flag, 1);
+}
+
 // The same for the coder's interleaved layout [position][stream] (stride_b == 1, stride_i == B): a block owns 64
 // streams x 64 positions and transposes through LDS, so that the scale reads (contiguous along positions) and the
 // index writes (contiguous along streams) are both coalesced - written straight, every 4-byte index lands in a
@@ -652,6 +712,28 @@ int licos_gc_build_indexes(const float *scales, const float *table, int levels, 
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(gc_build_indexes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), scales, table, levels,
                      scale_bound, indexes, stride_b, stride_i, n, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gc_pack_symbols(const float *y, const float *scales, const float *table, int levels, float scale_bound, int32_t *packed,
+                          int32_t *flag, int B, long n, void *stream) {
+  LICOS_REQUIRE(y && scales && table && packed && flag && levels > 0 && levels <= 65536 && B > 0 && n > 0, "gc_pack_symbols: bad arguments");
+  const long total = (long)B * n, quads = (total + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 65536 ? (quads + 255) / 256 : 65536);
+  hipLaunchKernelGGL(gc_host_words_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), y, scales, table, levels, scale_bound,
+                     packed, static_cast<uint8_t *>(nullptr), flag, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_gc_build_rows8(const float *scales, const float *table, int levels, float scale_bound, uint8_t *rows8, int B, long n,
+                         void *stream) {
+  LICOS_REQUIRE(scales && table && rows8 && levels > 0 && levels <= 256 && B > 0 && n > 0, "gc_build_rows8: bad arguments (at most 256 table rows)");
+  const long total = (long)B * n, quads = (total + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 65536 ? (quads + 255) / 256 : 65536);
+  hipLaunchKernelGGL(gc_host_words_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const float *>(nullptr),
+                     scales, table, levels, scale_bound, static_cast<int32_t *>(nullptr), rows8, static_cast<int32_t *>(nullptr), total);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -21,6 +21,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -119,7 +120,7 @@ long encode_stream(const int32_t *sym, const int32_t *idx, long stride, int n, i
 // issue width (measured: 3.5 -> ~1.2 ns per symbol and thread at K = 4).  Same arithmetic, same bytes as encode_stream.
 template <int K>
 void encode_streams(const int32_t *const (&sym)[K], const int32_t *const (&idx)[K], long stride, int n, int plane, const Tables &t,
-                    const EncRec *enc, uint32_t *const (&buf)[K], long cap_words, long (&nwords)[K]) {
+                    const EncRec *enc, uint32_t *const (&buf)[K], long cap_words, long (&nwords)[K], bool packed = false) {
   WordSink out[K];
   uint64_t x[K];
   int row[K], max_value[K], off[K], next_row_change[K];
@@ -181,12 +182,15 @@ void encode_streams(const int32_t *const (&sym)[K], const int32_t *const (&idx)[
 #pragma GCC unroll 8
       for (int k = 0; k < K; ++k) {
         if (__builtin_expect(bad[k], 0)) continue;
-        const int r = idx[k][(long)i * stride];
+        // packed (licos_rans_encode_host_packed): one word per symbol, row << 16 | (symbol & 0xFFFF) - half the bytes
+        // over PCIe when the words come from the device (idx[k] == sym[k] then)
+        const int32_t w = sym[k][(long)i * stride];
+        const int r = packed ? (int)((uint32_t)w >> 16) : idx[k][(long)i * stride];
         if (__builtin_expect((unsigned)r >= (unsigned)t.rows, 0)) { bad[k] = true; continue; }
         const EncRec *e_row = enc + (size_t)r * t.cdf_stride;
         const int maxv = t.cdf_len[r] - 2, o = t.offset[r];
         if (__builtin_expect(maxv < 0, 0)) { bad[k] = true; continue; }
-        int value = sym[k][(long)i * stride] - o;
+        int value = (packed ? (int)(int16_t)(uint16_t)(w & 0xFFFF) : w) - o;
         if (__builtin_expect((unsigned)value >= (unsigned)maxv, 0)) {
           const uint32_t raw = value < 0 ? (uint32_t)(-2 * (int64_t)value - 1) : (uint32_t)(2 * ((int64_t)value - maxv));
           int nb = 0;
@@ -360,8 +364,8 @@ int decode_stream(const uint8_t *data, long nbytes, int32_t *sym, const int32_t 
 
 // K streams in lockstep: see encode_streams.  A decode step is state -> cumulative value -> table search -> multiply ->
 // (rarely) one word in: ~25 dependent cycles alone.
-template <int K>
-void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], int32_t *const (&sym)[K], const int32_t *const (&idx)[K],
+template <int K, typename IdxT = int32_t>
+void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], int32_t *const (&sym)[K], const IdxT *const (&idx)[K],
                     long stride, int n, int plane, const Tables &t, const DecLut &lut, int (&rc)[K]) {
   WordSource in[K];
   uint64_t x[K];
@@ -626,12 +630,10 @@ inline int lockstep_width(int batch, int nthreads) {
 
 using namespace licos;
 
-extern "C" {
-
-int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
-                           int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
-                           int rows, const void *enc_table, uint8_t *out, long cap_bytes_per_stream, int64_t *nbytes,
-                           int batch, int nthreads) {
+static int encode_host(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
+                       int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
+                       int rows, const void *enc_table, uint8_t *out, long cap_bytes_per_stream, int64_t *nbytes,
+                       int batch, int nthreads, bool packed) {
   LICOS_REQUIRE(symbols && cdf && cdf_len && offset && enc_table && out && nbytes, "rans_encode_host: NULL buffer");
   LICOS_REQUIRE(n >= 0 && batch >= 0 && rows > 0 && cdf_stride > 1, "rans_encode_host: bad shape");
   LICOS_REQUIRE(indexes || plane > 0, "rans_encode_host: plane must be positive without explicit indexes");
@@ -664,13 +666,15 @@ int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long 
       ip[k] = indexes ? indexes + (size_t)(b0 + k) * sym_stride_b : nullptr;
       bp[k] = reinterpret_cast<uint32_t *>(out + (size_t)(b0 + k) * cap_bytes_per_stream);
     }
-    encode_streams<KK>(sp, ip, sym_stride_i, n, plane, t, enc, bp, cap_words, nw);
+    encode_streams<KK>(sp, ip, sym_stride_i, n, plane, t, enc, bp, cap_words, nw, packed);
     for (int k = 0; k < KK; ++k) finish(b0 + k, nw[k]);
   };
   Pool::instance().run(njobs, nthreads, [&](int j) {
     const int b0 = j * K, cnt = batch - b0 < K ? batch - b0 : K;
     if (cnt == 4) run_group(std::integral_constant<int, 4>{}, b0);
     else if (cnt == 2) run_group(std::integral_constant<int, 2>{}, b0);
+    else if (packed)
+      for (int k = 0; k < cnt; ++k) run_group(std::integral_constant<int, 1>{}, b0 + k);
     else
       for (int k = 0; k < cnt; ++k) {
         uint32_t *buf = reinterpret_cast<uint32_t *>(out + (size_t)(b0 + k) * cap_bytes_per_stream);
@@ -683,9 +687,10 @@ int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long 
   return LICOS_OK;
 }
 
-int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int32_t *indexes, long sym_stride_b,
-                           long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
-                           const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int batch, int nthreads) {
+template <typename IdxT>
+static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *indexes, long sym_stride_b,
+                       long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                       const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int batch, int nthreads) {
   LICOS_REQUIRE(in && byte_off && cdf && cdf_len && offset && symbols && status, "rans_decode_host: NULL buffer");
   LICOS_REQUIRE(n >= 0 && batch >= 0 && rows > 0 && cdf_stride > 1, "rans_decode_host: bad shape");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_host: plane must be positive without explicit indexes");
@@ -704,15 +709,26 @@ int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int
   const int njobs = (batch + K - 1) / K;
   auto one = [&](int b) {
     const long nb = (long)(byte_off[b + 1] - byte_off[b]);
-    note(nb < 0 ? 2 : decode_stream(in + byte_off[b], nb, symbols + (size_t)b * sym_stride_b,
-                                    indexes ? indexes + (size_t)b * sym_stride_b : nullptr, sym_stride_i, n, plane, t, lut));
+    if (nb < 0) return note(2);
+    if constexpr (std::is_same<IdxT, int32_t>::value) {
+      note(decode_stream(in + byte_off[b], nb, symbols + (size_t)b * sym_stride_b,
+                         indexes ? indexes + (size_t)b * sym_stride_b : nullptr, sym_stride_i, n, plane, t, lut));
+    } else {
+      const uint8_t *dp[1] = {in + byte_off[b]};
+      const long nbs[1] = {nb};
+      int32_t *sp[1] = {symbols + (size_t)b * sym_stride_b};
+      const IdxT *ip[1] = {indexes ? indexes + (size_t)b * sym_stride_b : nullptr};
+      int rc[1];
+      decode_streams<1, IdxT>(dp, nbs, sp, ip, sym_stride_i, n, plane, t, lut, rc);
+      note(rc[0]);
+    }
   };
   auto run_group = [&](auto kc, int b0) {
     constexpr int KK = decltype(kc)::value;
     const uint8_t *dp[KK];
     long nb[KK];
     int32_t *sp[KK];
-    const int32_t *ip[KK];
+    const IdxT *ip[KK];
     int rc[KK];
     for (int k = 0; k < KK; ++k) {
       nb[k] = (long)(byte_off[b0 + k + 1] - byte_off[b0 + k]);
@@ -724,7 +740,7 @@ int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int
       sp[k] = symbols + (size_t)(b0 + k) * sym_stride_b;
       ip[k] = indexes ? indexes + (size_t)(b0 + k) * sym_stride_b : nullptr;
     }
-    decode_streams<KK>(dp, nb, sp, ip, sym_stride_i, n, plane, t, lut, rc);
+    decode_streams<KK, IdxT>(dp, nb, sp, ip, sym_stride_i, n, plane, t, lut, rc);
     for (int k = 0; k < KK; ++k) note(rc[k]);
   };
   Pool::instance().run(njobs, nthreads, [&](int j) {
@@ -737,6 +753,38 @@ int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int
   if (worst.load() == 2) return fail(LICOS_EINVAL, "rans_decode_host: CDF row out of range or bad stream offsets");
   status[0] = worst.load();  // 1: some stream ended before all its symbols were decoded
   return LICOS_OK;
+}
+
+extern "C" {
+
+int licos_rans_encode_host(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
+                           int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
+                           int rows, const void *enc_table, uint8_t *out, long cap_bytes_per_stream, int64_t *nbytes,
+                           int batch, int nthreads) {
+  return encode_host(symbols, indexes, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_stride, cdf_len, offset, rows, enc_table, out,
+                     cap_bytes_per_stream, nbytes, batch, nthreads, false);
+}
+
+int licos_rans_encode_host_packed(const int32_t *packed, long stride_b, int n, const int32_t *cdf, int cdf_stride,
+                                  const int32_t *cdf_len, const int32_t *offset, int rows, const void *enc_table, uint8_t *out,
+                                  long cap_bytes_per_stream, int64_t *nbytes, int batch, int nthreads) {
+  return encode_host(packed, packed, stride_b, 1, n, 0, cdf, cdf_stride, cdf_len, offset, rows, enc_table, out, cap_bytes_per_stream,
+                     nbytes, batch, nthreads, true);
+}
+
+int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int32_t *indexes, long sym_stride_b,
+                           long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                           const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int batch, int nthreads) {
+  return decode_host<int32_t>(in, byte_off, indexes, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_stride, cdf_len, offset, rows,
+                              symbols, status, batch, nthreads);
+}
+
+int licos_rans_decode_host_rows8(const uint8_t *in, const int64_t *byte_off, const uint8_t *rows8, long stride_b, int n,
+                                 const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int rows,
+                                 int32_t *symbols, int32_t *status, int batch, int nthreads) {
+  LICOS_REQUIRE(rows8, "rans_decode_host_rows8: NULL rows");
+  return decode_host<uint8_t>(in, byte_off, rows8, stride_b, 1, n, 0, cdf, cdf_stride, cdf_len, offset, rows, symbols, status, batch,
+                              nthreads);
 }
 
 }  // extern "C"

@@ -613,6 +613,28 @@ def gc_build_indexes(scales, table, scale_bound, indexes, stride_b, stride_i):
     return indexes
 
 
+def gc_pack_symbols(y, scales, table, scale_bound, packed, flag):
+    """packed int32 [B][n] (device) = table row << 16 | (round(y) & 0xFFFF); flag int32 [1] (device) |= 1 on a symbol
+    outside int16 - the host coder's compact input (rans_encode_host_packed)."""
+    _dev(y, scales, table, packed, flag)
+    b = scales.shape[0]
+    n = scales[0].numel()
+    rc = _lib.load().licos_gc_pack_symbols(_p(_f32(y)), _p(_f32(scales)), _p(_f32(table)), table.numel(), scale_bound, _p(packed),
+                                           _p(flag), b, n, _stream())
+    _lib.check(rc, "gc_pack_symbols")
+    return packed
+
+
+def gc_build_rows8(scales, table, scale_bound, rows8):
+    """rows8 uint8 [B][n] (device): the table row of every symbol, for rans_decode_host_rows8."""
+    _dev(scales, table, rows8)
+    b = scales.shape[0]
+    n = scales[0].numel()
+    rc = _lib.load().licos_gc_build_rows8(_p(_f32(scales)), _p(_f32(table)), table.numel(), scale_bound, _p(rows8), b, n, _stream())
+    _lib.check(rc, "gc_build_rows8")
+    return rows8
+
+
 def scale_f32(x, alpha, inv_alpha_dev=None):
     """In place x *= alpha (or alpha / inv_alpha_dev[0])."""
     _dev(x, inv_alpha_dev)
@@ -824,6 +846,47 @@ def rans_encode_host(symbols, n, plane, cdf, cdf_len, offset, enc_table, indexes
         cap = 8 * n + 16  # worst case: under two words per symbol
     _lib.check(rc, "rans_encode_host")
     return out, nbytes
+
+
+def rans_encode_host_packed(packed, n, cdf, cdf_len, offset, enc_table, nthreads=None):
+    """Host coder on packed words (ops.gc_pack_symbols): int32 numpy [B][n].  Returns (out uint8 [B][cap], nbytes int64 [B])."""
+    pk, pp = _np_i32(packed)
+    b = pk.shape[0]
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    cap = 4 * (n // 2 + 64)
+    for attempt in range(2):
+        out = np.empty((b, cap), dtype=np.uint8)
+        nbytes = np.zeros(b, dtype=np.int64)
+        rc = _lib.load().licos_rans_encode_host_packed(pp, n, n, cp, cdf_a.shape[1], lp, op, cdf_a.shape[0],
+                                                       ctypes.c_void_p(enc_table.ctypes.data), ctypes.c_void_p(out.ctypes.data), cap,
+                                                       ctypes.c_void_p(nbytes.ctypes.data), b, nthreads)
+        if rc != -4 or attempt == 1:
+            break
+        cap = 8 * n + 16  # worst case: under two words per symbol
+    _lib.check(rc, "rans_encode_host_packed")
+    return out, nbytes
+
+
+def rans_decode_host_rows8(data, byte_off, rows8, n, cdf, cdf_len, offset, batch, out, nthreads=None):
+    """Host decoder with one table-row byte per symbol (ops.gc_build_rows8): rows8 uint8 numpy [B][n], out int32 [B][n].
+    Returns the status (1: a stream ended early)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off64 = np.ascontiguousarray(byte_off, dtype=np.int64)
+    rows8 = np.ascontiguousarray(rows8, dtype=np.uint8)
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    status = np.zeros(1, dtype=np.int32)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    assert out.dtype == np.int32 and out.flags["C_CONTIGUOUS"] and out.shape == (batch, n) and rows8.shape == (batch, n)
+    rc = _lib.load().licos_rans_decode_host_rows8(ctypes.c_void_p(data.ctypes.data), ctypes.c_void_p(off64.ctypes.data),
+                                                  ctypes.c_void_p(rows8.ctypes.data), n, n, cp, cdf_a.shape[1], lp, op, cdf_a.shape[0],
+                                                  ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(status.ctypes.data), batch, nthreads)
+    _lib.check(rc, "rans_decode_host_rows8")
+    return int(status[0])
 
 
 def rans_decode_host(data, byte_off, n, plane, cdf, cdf_len, offset, batch, indexes=None, nthreads=None, out=None):

@@ -172,3 +172,17 @@ def test_hyper_codec_host_share_changes_nothing(monkeypatch):
         with pytest.raises(ValueError):
             net.decompress(bad, c0["shape"])
         torch.cuda.synchronize()
+        # latents beyond 16 bits: the host's packed words (row << 16 | symbol) cannot carry them - the call is coded on the
+        # device as a whole, same strings; the decoder's host share (rows down, 32-bit symbols up) is not concerned
+        net.g_a[6].weight.mul_(4000.0)
+        share["enc"], share["dec"] = 0, 0
+        big0 = net.compress(x)
+        ymax = max(abs(int(v)) for v in net.decompress(big0["strings"], big0["shape"])["x_hat"].shape)  # (shape only: the call must work)
+        assert ymax > 0
+        share["enc"], share["dec"] = 6, 6
+        big = net.compress(x)
+        assert sum(n for _, n, _, _ in big["strings"][0].segments) == 21  # no tile went to the host
+        assert [bytes(s_) for s_ in big["strings"][0]] == [bytes(s_) for s_ in big0["strings"][0]]
+        assert max(len(s_) for s_ in big["strings"][0]) > 2 * max(len(s_) for s_ in ys0)  # (escapes everywhere: the latents are large)
+        assert torch.equal(net.decompress(big["strings"], big["shape"])["x_hat"],
+                           net.decompress([[bytes(s_) for s_ in lst] for lst in big0["strings"]], big0["shape"])["x_hat"])

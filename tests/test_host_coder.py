@@ -107,3 +107,39 @@ def test_host_decoder_chained_bypass_count_and_truncation():
     assert st == 1
     dec, st = ops.rans_decode_host(np.zeros(4, dtype=np.uint8), np.array([0, 0]), n, 8, cdf, cl, off, 1)
     assert st == 1 and not dec.any()
+
+
+@pytest.mark.parametrize("batch,threads", [(1, 1), (7, 3), (22, 8)])
+def test_host_coder_compact_forms_equal_the_oracle(batch, threads):
+    """licos_rans_encode_host_packed (one word per symbol: row << 16 | symbol & 0xFFFF) and licos_rans_decode_host_rows8
+    (one row byte per symbol) - what crosses PCIe when the host cores take a share of a scale-hyperprior call - give the
+    oracle's bytes and symbols: explicit rows changing from symbol to symbol, escapes on both sides up to the 16-bit ends,
+    groups of 4, 2 and single streams, truncated streams."""
+    cdf, cl, off, table = _tables(seed=batch)
+    rng = np.random.default_rng(100 + batch)
+    n = 3001
+    idx = rng.integers(0, 192, size=(batch, n)).astype(np.int32)
+    sym = np.rint(rng.standard_normal((batch, n)) * 7).astype(np.int32)
+    sym[0, 0], sym[0, 9], sym[-1, n - 1], sym[-1, 11] = 32767, -32768, -1234, 4321
+    packed = ((idx.astype(np.int64) << 16) | (sym.astype(np.int64) & 0xFFFF)).astype(np.uint32).view(np.int32)
+    out, nb = ops.rans_encode_host_packed(packed, n, cdf, cl, off, table, nthreads=threads)
+    got = _strings(out, nb)
+    assert got == [rans.encode_with_indexes(sym[b], idx[b], cdf, cl, off) for b in range(batch)]
+    o2, n2 = ops.rans_encode_host(sym, n, 0, cdf, cl, off, table, indexes=idx, nthreads=threads)
+    assert _strings(o2, n2) == got
+    data = np.frombuffer(b"".join(got), dtype=np.uint8)
+    byte_off = np.concatenate(([0], np.cumsum(nb))).astype(np.int64)
+    dec = np.full((batch, n), -7, dtype=np.int32)
+    assert ops.rans_decode_host_rows8(data, byte_off, idx.astype(np.uint8), n, cdf, cl, off, batch, out=dec, nthreads=threads) == 0
+    assert np.array_equal(dec, sym)
+    # the last stream cut short: status 1, the other streams intact
+    cut = byte_off.copy()
+    cut[-1] -= 8
+    dec2 = np.full((batch, n), -7, dtype=np.int32)
+    assert ops.rans_decode_host_rows8(data[: cut[-1]], cut, idx.astype(np.uint8), n, cdf, cl, off, batch, out=dec2, nthreads=threads) == 1
+    assert np.array_equal(dec2[:-1], sym[:-1])
+    # a row outside the table is an error, not a read outside it
+    bad = packed.copy()
+    bad[0, 5] = (200 << 16) | 3
+    with pytest.raises(Exception):
+        ops.rans_encode_host_packed(bad, n, cdf, cl, off, table, nthreads=threads)

@@ -45,6 +45,10 @@ with torch.no_grad():
             print("  enc factor %.2f" % codec._host_factor["enc"])
             for e in tr:
                 print("  ", e[:2], ["%.1f" % (1e3 * (v - t0)) if e[0] not in ("hyper-enc", "hyper-dec") else v for v in e[2:]])
+        ms_ = torch.cuda.memory_stats()
+        print("   reserved %.1f GB, allocated peak %.1f GB, alloc retries %d, hipMalloc calls %d, hipFree calls %d" % (
+            ms_["reserved_bytes.all.current"] / 2**30, ms_["allocated_bytes.all.peak"] / 2**30, ms_["num_alloc_retries"],
+            ms_["segment.all.allocated"], ms_["segment.all.freed"]))
         print("iter %d: compress %.1f ms, decompress %.1f ms, %.0f tiles/s" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), B / (t2 - t0)), flush=True)
 nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
 for k, evs in codec.coder_events.items():

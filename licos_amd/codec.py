@@ -546,8 +546,15 @@ def _drain(dev, copy, coded, parts):
 
 
 def hyper_fast_path(net, batch):
-    """The chunk-pipelined scale-hyperprior codec applies: device coder placement and a decoder image that fits LDS."""
-    return (not ops.host_coder_preferred(batch)) and net.gaussian_conditional.coder_image() is not None
+    """The chunk-pipelined scale-hyperprior codec applies: a decoder image that fits LDS, and either device coder
+    placement (large calls) or a host-coded call of at least one full sub-chunk (4 tiles per host thread), which runs
+    the same pipeline with every tile in the host's share - transforms, PCIe and host coding overlap sub-chunk by
+    sub-chunk instead of following one another as in the plain module path."""
+    if net.gaussian_conditional.coder_image() is None:
+        return False
+    if not ops.host_coder_preferred(batch):
+        return True
+    return HOST_SPLIT and batch >= 4 * ops.host_threads()
 
 
 def hyper_retry_chunk(chunk, ny):
@@ -576,6 +583,8 @@ def hyper_host_share(batch, direction="enc"):
     hipMalloc, 30 ms)."""
     if ops.HOST_CODER == "0" or not HOST_SPLIT:
         return 0
+    if ops.host_coder_preferred(batch):  # a mid-size call (or LICOS_HOST_CODER=1): every tile, no device coder launch at all
+        return batch
     if "LICOS_HYPER_SHARE" in os.environ:  # dev probe
         return min(int(os.environ["LICOS_HYPER_SHARE"]), batch // 3)
     threads = ops.host_threads()
@@ -816,21 +825,35 @@ def decompress_hyper(net, strings, shape, chunk=512):
             covered = s0 + pieces[-1][1]
         pieces += [(covered + t0, m) for (t0, m) in _chunks(n_dev - covered, chunk)]  # tiles the host encoded but the device decodes
     status = torch.zeros(1, device=dev, dtype=torch.int32)
-    zsym = torch.empty((nz, B), device=dev, dtype=torch.int32)
-    # z: every tile's string in ONE launch (2 ms whatever the batch; a launch per piece would queue them up on this stream)
-    zup = _upload(zstrs, pieces + ([(n_dev, n_host)] if n_host else []), dev)
-    if len(zup) > 1:  # (every string is a whole number of 32-bit words: the pieces concatenate without padding)
-        zdata = torch.cat([data for (data, _) in zup])
-        base, offs = 0, []
-        for (data, off) in zup:
-            offs.append(off[:-1] + base)
-            base += data.numel()
-        zoff_all = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
+    if n_dev == 0:
+        # a host-coded call: the z strings too (a device launch would cost its 2 ms of latency for 0.1 ms of host work)
+        hz = eb.coder_tables_host()
+        zlens = np.fromiter((len(b_) for b_ in zstrs), dtype=np.int64, count=B)
+        zbyte_off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(zlens, out=zbyte_off[1:])
+        zstage = _pinned_i32("hzd", B, nz)
+        _, zbad = ops.rans_decode_host(np.frombuffer(b"".join(zstrs), dtype=np.uint8), zbyte_off, nz, zplane, hz[0], hz[1], hz[2], B,
+                                       out=zstage.numpy())
+        if zbad != 0:
+            raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
+        zsym = zstage.to(dev, non_blocking=True)
+        z_hat = ops.eb_dequantize(zsym, nz, 1, med, B, N, h, w)
     else:
-        zdata, zoff_all = zup[0]
-    _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
-                                                           status=status, off_offset=0))
-    z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
+        zsym = torch.empty((nz, B), device=dev, dtype=torch.int32)
+        # z: every tile's string in ONE launch (2 ms whatever the batch; a launch per piece would queue them up on this stream)
+        zup = _upload(zstrs, pieces + ([(n_dev, n_host)] if n_host else []), dev)
+        if len(zup) > 1:  # (every string is a whole number of 32-bit words: the pieces concatenate without padding)
+            zdata = torch.cat([data for (data, _) in zup])
+            base, offs = 0, []
+            for (data, off) in zup:
+                offs.append(off[:-1] + base)
+                base += data.numel()
+            zoff_all = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
+        else:
+            zdata, zoff_all = zup[0]
+        _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,
+                                                               status=status, off_offset=0))
+        z_hat = ops.eb_dequantize(zsym, 1, B, med, B, N, h, w)
     yup = _upload(ystrs, pieces, dev, id_base=len(pieces) + 1)  # staging slots behind the z pieces': no slot is shared in a call
     fp16 = net.precision == "fp16"
     st = engine.stages(net.g_s)

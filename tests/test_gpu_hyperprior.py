@@ -157,7 +157,7 @@ def test_hyper_codec_host_share_changes_nothing(monkeypatch):
         ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
         ys0, zs0 = [bytes(s_) for s_ in c0["strings"][0]], [bytes(s_) for s_ in c0["strings"][1]]
         monkeypatch.setattr(ops, "host_threads", lambda: 2)
-        for enc, dec in ((5, 5), (9, 3), (3, 9), (0, 6), (6, 0), (7, 7)):
+        for enc, dec in ((5, 5), (9, 3), (3, 9), (0, 6), (6, 0), (7, 7), (21, 21), (21, 0), (0, 21)):
             share["enc"], share["dec"] = enc, dec
             c = net.compress(x)
             assert [bytes(s_) for s_ in c["strings"][0]] == ys0 and [bytes(s_) for s_ in c["strings"][1]] == zs0, (enc, dec)
@@ -186,3 +186,35 @@ def test_hyper_codec_host_share_changes_nothing(monkeypatch):
         assert max(len(s_) for s_ in big["strings"][0]) > 2 * max(len(s_) for s_ in ys0)  # (escapes everywhere: the latents are large)
         assert torch.equal(net.decompress(big["strings"], big["shape"])["x_hat"],
                            net.decompress([[bytes(s_) for s_ in lst] for lst in big0["strings"]], big0["shape"])["x_hat"])
+
+
+def test_hyper_codec_mid_size_calls_run_the_host_pipeline(monkeypatch, request):
+    """A host-coded call of at least 4 tiles per host thread takes the sub-chunk pipeline with every tile in the host's
+    share (codec.hyper_fast_path / hyper_host_share through the real policy): the plain module path's strings and tiles."""
+    from licos_amd import codec, ops
+    if ops.HOST_CODER == "0":
+        pytest.skip("device-coder placement: the policy under test is the host's")
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    monkeypatch.setattr(ops, "host_threads", lambda: 2)
+    torch.manual_seed(5)
+    net = licos_amd.get_model("bmshj2018-hyperprior", False, 13, 1).to(DEV).eval().set_precision("fp16")
+    with torch.no_grad():
+        licos_amd.synthetic.make_trained_like(net, seed=4)
+    net.update(force=True)
+    x = licos_amd.synthetic.tiles(19, 13, 128, seed=2, kind="s2-merged", device=DEV)
+    assert ops.host_coder_preferred(19) and codec.hyper_fast_path(net, 19) and not codec.hyper_fast_path(net, 7)
+    assert codec.hyper_host_share(19, "enc") == 19 == codec.hyper_host_share(19, "dec")
+    calls = []
+    real = codec.compress_hyper
+    monkeypatch.setattr(codec, "compress_hyper", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        c = net.compress(x)
+        d = net.decompress(c["strings"], c["shape"])["x_hat"]
+        assert calls == [1]
+        monkeypatch.setattr(codec, "HOST_SPLIT", False)  # the plain module path: transform, copy, one host coder call
+        assert not codec.hyper_fast_path(net, 19)
+        c0 = net.compress(x)
+        d0 = net.decompress(c0["strings"], c0["shape"])["x_hat"]
+        assert calls == [1]
+    assert [[bytes(s_) for s_ in lst] for lst in c["strings"]] == [[bytes(s_) for s_ in lst] for lst in c0["strings"]]
+    assert torch.equal(d, d0)

@@ -191,6 +191,13 @@ int licos_gc_likelihood(const float *v, const float *scales, float *lik, float s
  * coder's addressing (element (b, i) at b*stride_b + i*stride_i, i = c*HW + p). */
 int licos_gc_build_indexes(const float *scales, const float *table, int levels, float scale_bound, int32_t *indexes,
                            long stride_b, long stride_i, int B, long n, void *stream);
+/* 16-bit symbols in the plain [stream][position] layout for the tiles the HOST codes (EntropyBottleneck.compress /
+ * decompress, [CAI] entropy_models.py: symbols = round(y - median), y_hat = symbols + median) - half the PCIe bytes of the
+ * int32 form.  symbols16: flag[0] |= 1 when a symbol does not fit int16 (use licos_eb_quantize then).
+ * dequantize16: y_nchw fp32 [B][C][H][W] and / or y_blk16 fp16 [B][ceil(C/16)][H*W][16] (needs H*W % 64 == 0). */
+int licos_eb_symbols16(const float *y, const float *medians, int16_t *symbols, int32_t *flag, int B, int C, int HW, void *stream);
+int licos_eb_dequantize16(const int16_t *symbols, const float *medians, float *y_nchw, void *y_blk16, int B, int C, int H, int W,
+                          void *stream);
 /* What the host coder (licos_rans_*_host_packed / _rows8 below) needs of a y stream, in as few bytes as PCIe allows, when
  * the host cores code part of a scale-hyperprior call beside the device (GaussianConditional.compress / decompress,
  * [CAI] entropy_models.py: indexes = build_indexes(scales), symbols = round(y)).  Plain [stream][position] layout.
@@ -280,6 +287,14 @@ int licos_rans_encode_host_packed(const int32_t *packed, long stride_b, int n, c
 int licos_rans_decode_host_rows8(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const uint8_t *rows8, long stride_b, int n,
                                  const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int rows,
                                  int32_t *symbols, int32_t *status, int B, int nthreads);
+/* ... and on 16-bit symbols [B][n] with channel-plane rows (licos_eb_symbols16 / licos_eb_dequantize16).  decode:
+ * status[0] = 3 when a decoded value does not fit int16 (decode the batch again with licos_rans_decode_host). */
+int licos_rans_encode_host_sym16(const int16_t *symbols, long stride_b, int n, int plane, const int32_t *cdf, int cdf_stride,
+                                 const int32_t *cdf_len, const int32_t *offset, int rows, const void *enc_table, uint8_t *out,
+                                 long cap_bytes_per_stream, int64_t *nbytes, int B, int nthreads);
+int licos_rans_decode_host_sym16(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, long stride_b, int n, int plane,
+                                 const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int rows,
+                                 int16_t *symbols, int32_t *status, int B, int nthreads);
 /* gathers each stream's words (in stream order) into one packed little-endian
  * byte buffer: stream b occupies out[byte_off[b] .. byte_off[b] + 4*nwords[b]).
  * byte_off[B] = exclusive prefix sum of 4*nwords (computed by the caller). */

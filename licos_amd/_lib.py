@@ -62,6 +62,10 @@ SIGNATURES = {
     "licos_eb_encode_prepare": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "licos_gc_likelihood": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp]),
     "licos_gc_build_indexes": (_i, [_vp, _vp, _i, _f, _vp, _l, _l, _i, _l, _vp]),
+    "licos_eb_symbols16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "licos_eb_dequantize16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "licos_rans_encode_host_sym16": (_i, [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i]),
+    "licos_rans_decode_host_sym16": (_i, [_vp, _vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i]),
     "licos_gc_pack_symbols": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _i, _l, _vp]),
     "licos_gc_build_rows8": (_i, [_vp, _vp, _i, _f, _vp, _i, _l, _vp]),
     "licos_rans_encode_host_packed": (_i, [_vp, _l, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i]),

@@ -126,6 +126,15 @@ SIMPLE_BATCH = 8  # calls of up to this many tiles skip the sub-chunk pipeline (
 # dequantise kernels' own stores and loads on the page-locked staging buffer (LICOS_ZERO_COPY=1; measured equal for small
 # batches and slower at 1024 tiles: 13.2 vs 10.9 ms)
 ZERO_COPY = os.environ.get("LICOS_ZERO_COPY", "0") == "1"
+# The host's tiles cross PCIe as 16-bit symbols (licos_eb_symbols16 / licos_eb_dequantize16, licos_rans_*_host_sym16): the
+# copies of a sub-chunk are blit kernels that share the CUs with the next sub-chunk's transforms, half the bytes are half
+# of that.  A symbol outside 16 bits is flagged by the quantise kernel / the host decoder and the call (the sub-chunk)
+# falls back to the 32-bit form.  LICOS_SYM16=0 switches it off (A/B).
+SYM16 = os.environ.get("LICOS_SYM16", "1") != "0"
+
+
+def _pinned_i16(role, rows, cols):
+    return _pinned_i32(role, rows, (cols + 1) // 2).view(torch.int16)[:, :cols]
 
 
 # Feedback: what the host coder actually delivered in this process's recent calls, as a factor on HOST_NS (1 = nominal).
@@ -153,16 +162,15 @@ def host_capacity(direction):
 def host_share(batch, direction):
     """How many tiles of a call of `batch` tiles the host codes.  Everything up to the host's capacity for the direction
     (a thousand tiles encoding, four hundred decoding at 16 threads: the device coder's launch latency alone is longer
-    than the host takes); of a decode call of up to four times that, its first `capacity` tiles - the synthesis
-    transform starts on them while the one device launch the call needs anyway covers the rest; nothing of larger calls.
-    `capacity` follows the rate the host coder delivered in this process's recent calls (_note_host_rate).
-    Measured and left out, twice: the exposed end of LARGE calls (the last thousand tiles of a 16 384-tile compress, the
-    first four hundred of its decompress).  First form (all GPU work queued, then the host codes): -3 ms of 200 on a
-    quiet host, +14 ms on a loaded one (profiles/r04_split_probe_box1.log / _box2.log).  Second form (sub-chunk k queued
-    before k - 1 is coded, host tiles synthesised on their own stream, share sized by the measured host rate): 210.8 ms
-    per 16 384-tile step against 200.6 - 201.5 without it, twice each on one box - the host pipeline moves ~100 tiles per
-    ms where the device transforms 185, so a thousand tiles at the end of a call take longer through it than the 7-ms
-    device launch they were meant to hide."""
+    than the host takes).  Of a larger call, the tiles at its exposed end: the first `capacity` tiles of a decode - the
+    synthesis transform starts on them while the first device launch runs - and the last 0.7 x `capacity` of an encode
+    (the host pipeline moves ~100 tiles per ms: what it finishes beside the last 7-ms device launch and that launch's
+    drain).  `capacity` follows the rate the host coder delivered in this process's recent calls (_note_host_rate).
+    The large-call split was measured and left out twice earlier in round 4 (+10 ms per 16 384-tile step); the loss was
+    not the split: a piece of decompress that joins a packed segment with the tiles the host encoded built its end offset
+    with `torch.tensor([n], device=...)`, a blocking copy that waited for every decode launch queued so far (fixed:
+    decompress_chunked).  With that gone: 16 384 tiles 201.3 -> 195.6 ms on one box, 204.5 -> 200.7 on another; 4 096
+    tiles 63.3 -> 58.7 ms (tools/batch_probe.py, profiles/r04_large_call_split.log)."""
     if ops.HOST_CODER == "0":
         return 0
     if ops.HOST_CODER == "1" or ops.host_coder_preferred(batch):
@@ -172,9 +180,7 @@ def host_share(batch, direction):
     cap = host_capacity(direction)
     if batch <= cap:
         return batch
-    if direction == "dec" and batch <= 4 * cap:
-        return cap
-    return 0
+    return cap if direction == "dec" else int(0.7 * cap)
 
 
 _pinned = {}
@@ -190,7 +196,7 @@ def _pinned_i32(role, rows, cols):
     return buf[:need].view(rows, cols)
 
 
-def compress_chunked(net, x, chunk=1024, cap_words=None):
+def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
     """FactorizedPrior.compress for any batch size and either precision (`net.g_a` dispatches on it).  Tiles
     [0, B - H) go through the device coder in pipeline chunks, the last H = host_share(B) tiles through the host coder in
     sub-chunks (see "split placement" above); the strings do not depend on the placement."""
@@ -288,14 +294,23 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
     if n_host and not overflow:
         hcdf, hlen, hoff, htable = eb.coder_tables_host()
         sub = max(1, HOST_SUB * ops.host_threads())
+        subs = list(_ramp(n_host, 2 * ops.host_threads(), sub))
         stage = None
+        use16 = (SYM16 if sym16 is None else sym16) and not ZERO_COPY
+        hflag = torch.zeros(len(subs), device=dev, dtype=torch.int32) if use16 else None
+        st_f = _pinned_i32("ef", 1, max(64, len(subs)))[0] if use16 else None
 
         def host_encode(entry):
-            (t0, m, _keep, landed) = entry
+            (k, t0, m, _keep, landed) = entry
             w0 = time.perf_counter()
             landed.synchronize()
             w1 = time.perf_counter()
-            out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
+            if use16:
+                if int(st_f[k]) != 0:
+                    raise _HostRange()
+                out, nbytes = ops.rans_encode_host_sym16(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
+            else:
+                out, nbytes = ops.rans_encode_host(stage[t0:t0 + m].numpy(), nsym, plane, hcdf, hlen, hoff, htable)
             w2 = time.perf_counter()
             _note_host_rate("enc", m, nsym, w2 - w1)
             strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
@@ -304,21 +319,25 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
 
         pending = None
         try:
-            for (t0, m) in _ramp(n_host, 2 * ops.host_threads(), sub):
+            for k, (t0, m) in enumerate(subs):
                 y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
                 if shape is None:
                     shape = tuple(y.shape[-2:])
                     nsym, plane = y[0].numel(), y[0, 0].numel()
                 if stage is None:
-                    stage = _pinned_i32("enc", n_host, nsym)
+                    stage = _pinned_i16("enc16", n_host, nsym) if use16 else _pinned_i32("enc", n_host, nsym)
                 if ZERO_COPY:
                     ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
                     landed = torch.cuda.Event()
                     landed.record(main)
-                    entry = (t0, m, y, landed)
+                    entry = (k, t0, m, y, landed)
                 else:
-                    hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
-                    ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
+                    if use16:
+                        hsym = torch.empty((m, nsym), device=dev, dtype=torch.int16)
+                        ops.eb_symbols16(y.contiguous(), med, hsym, hflag[k:k + 1])
+                    else:
+                        hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
+                        ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
                     ready = torch.cuda.Event()
                     ready.record(main)
                     # (a stream of its own: on the drains' copy stream these copies would queue up behind / in front of
@@ -326,14 +345,20 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
                     with torch.cuda.stream(hcopy):
                         hcopy.wait_event(ready)
                         stage[t0:t0 + m].copy_(hsym, non_blocking=True)
+                        if use16:
+                            st_f[k:k + 1].copy_(hflag[k:k + 1], non_blocking=True)
                         landed = torch.cuda.Event()
                         landed.record(hcopy)
-                    entry = (t0, m, hsym, landed)
+                    entry = (k, t0, m, hsym, landed)
                 if pending is not None:
                     host_encode(pending)
                 pending = entry
             if pending is not None:
                 host_encode(pending)
+        except _HostRange:  # a symbol outside 16 bits: the whole call again with 32-bit symbols for the host's tiles
+            torch.cuda.synchronize(dev)
+            del queued
+            return compress_chunked(net, x, chunk=chunk, cap_words=cap_words, sym16=False)
         except BaseException:
             torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffer: let them land
             raise
@@ -344,7 +369,7 @@ def compress_chunked(net, x, chunk=1024, cap_words=None):
         if cap_words >= 2 * nsym + 8:
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del queued
-        return compress_chunked(net, x, chunk=chunk, cap_words=2 * nsym + 8)
+        return compress_chunked(net, x, chunk=chunk, cap_words=2 * nsym + 8, sym16=sym16)
     main.wait_stream(side)
     main.wait_stream(copy)
     main.wait_stream(hcopy)
@@ -425,12 +450,14 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             if len(ups) == 1:
                 data, byte_off = ups[0]
             else:  # (every string is a whole number of 32-bit words: the parts concatenate without padding)
+                # (no scalar tensor for the end offset: building one is a blocking copy that waits for every decode launch
+                # queued on this stream so far - 10 ms of a 16 384-tile call whose last piece is such a join)
                 base, offs = 0, []
-                for (d_, o_) in ups:
-                    offs.append(o_[:-1] + base)
+                for j, (d_, o_) in enumerate(ups):
+                    offs.append((o_ if j == len(ups) - 1 else o_[:-1]) + base)
                     base += int(d_.numel())
                 data = torch.cat([d_ for (d_, _) in ups])
-                byte_off = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
+                byte_off = torch.cat(offs)
             if image is not None:
                 ops.rans_decode_image(data, byte_off, rows, nsym, image[0], image[1], sym, 1, n_dev, n, status=status,
                                       sym_offset=s0 - n_host, rows_shared=True)
@@ -454,6 +481,15 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             y_hat = ops.eb_dequantize(symbols, stride_b, stride_i, med, n, C, h, w, sym_offset=sym_offset)
             x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
 
+    def synthesise16(s0, n, symbols16):  # 16-bit symbols [stream][position] (the host's tiles)
+        if fp16:
+            y_blk = torch.empty((n, (C + 15) // 16, h, w, 16), device=dev, dtype=torch.float16)  # (every channel slot is written)
+            ops.eb_dequantize16(symbols16, med, n, C, h, w, want_nchw=False, blk16=y_blk)
+            engine.run_chain_fp16(net.g_s, x_blk=y_blk, clamp01=True, out=x_hat[s0:s0 + n])
+        else:
+            y_hat = ops.eb_dequantize16(symbols16, med, n, C, h, w)
+            x_hat[s0:s0 + n] = net.g_s(y_hat).detach().clamp_(0, 1)
+
     def synthesise_device_pieces():
         for (s0, n, _), ev in zip(pieces, events):
             main.wait_event(ev)
@@ -467,7 +503,9 @@ def decompress_chunked(net, strings, shape, chunk=1024):
     if n_host:
         import contextlib
         hcdf, hlen, hoff, _ = eb.coder_tables_host()
-        stage = _pinned_i32("dec", n_host, nsym)
+        use16 = SYM16 and not ZERO_COPY and (not fp16 or (h * w) % 64 == 0)
+        stage = _pinned_i32("dec", n_host, nsym) if not use16 else None
+        stage16 = _pinned_i16("dec16", n_host, nsym) if use16 else None
         sub = max(1, HOST_SUB * ops.host_threads())
         hsyn = _stream(dev, "hostsyn") if pieces else None
         if hsyn is not None:
@@ -481,8 +519,16 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             np.cumsum(lens, out=byte_off[1:])
             data = np.frombuffer(b"".join(part), dtype=np.uint8)
             w1 = time.perf_counter()
+            wide = not use16
             try:
-                _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
+                if use16:
+                    bad = ops.rans_decode_host_sym16(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage16[t0:t0 + m].numpy())
+                    if bad == 3:  # a value outside 16 bits: this sub-chunk again, 32-bit symbols
+                        wide = True
+                        if stage is None:
+                            stage = _pinned_i32("dec", n_host, nsym)
+                if wide:
+                    _, bad = ops.rans_decode_host(data, byte_off, nsym, plane, hcdf, hlen, hoff, m, out=stage[t0:t0 + m].numpy())
             except BaseException:
                 torch.cuda.synchronize(dev)  # earlier sub-chunks' uploads still read the shared page-locked buffer
                 raise
@@ -492,8 +538,12 @@ def decompress_chunked(net, strings, shape, chunk=1024):
                 torch.cuda.synchronize(dev)  # nothing of this call may still be reading its buffers when the exception unwinds
                 raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")
             with (torch.cuda.stream(hsyn) if hsyn is not None else contextlib.nullcontext()):
-                hsym = stage[t0:t0 + m] if ZERO_COPY else stage[t0:t0 + m].to(dev, non_blocking=True)
-                synthesise(t0, m, hsym, nsym, 1)
+                if wide:
+                    hsym = stage[t0:t0 + m] if ZERO_COPY else stage[t0:t0 + m].to(dev, non_blocking=True)
+                    synthesise(t0, m, hsym, nsym, 1)
+                else:
+                    hsym = stage16[t0:t0 + m].to(dev, non_blocking=True)
+                    synthesise16(t0, m, hsym)
             keep.append((hsym,))
             if host_trace is not None:
                 host_trace.append(("dec", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
@@ -845,10 +895,10 @@ def decompress_hyper(net, strings, shape, chunk=512):
         if len(zup) > 1:  # (every string is a whole number of 32-bit words: the pieces concatenate without padding)
             zdata = torch.cat([data for (data, _) in zup])
             base, offs = 0, []
-            for (data, off) in zup:
-                offs.append(off[:-1] + base)
+            for j, (data, off) in enumerate(zup):
+                offs.append((off if j == len(zup) - 1 else off[:-1]) + base)
                 base += data.numel()
-            zoff_all = torch.cat(offs + [torch.tensor([base], device=dev, dtype=torch.int64)])
+            zoff_all = torch.cat(offs)
         else:
             zdata, zoff_all = zup[0]
         _timed_coder("z_decode", lambda: ops.rans_decode_batch(zdata, zoff_all, 1, B, nz, zplane, zcdf, zlen, zoff, zsym, B,

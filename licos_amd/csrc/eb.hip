@@ -419,6 +419,75 @@ __global__ void gc_build_indexes_kernel(const float *__restrict__ scales, const 
   }
 }
 
+// 16-bit symbols in the plain [stream][position] layout, for the tiles the HOST codes (codec.compress_chunked /
+// decompress_chunked: half the bytes of the int32 form over PCIe, whose copies are blit kernels that share the CUs with
+// the transforms).  quantise: 4 positions per thread; `flag` is raised when a symbol does not fit (the caller then uses
+// the 32-bit form).
+__global__ __launch_bounds__(256) void eb_symbols16_kernel(const float *__restrict__ y, const float *__restrict__ medians,
+                                                           int16_t *__restrict__ sym, int32_t *__restrict__ flag, int C, int HW,
+                                                           long total) {
+  const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(sym) & 7) == 0;
+  bool over = false;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long)gridDim.x * blockDim.x * 4) {
+    const int m = total - e < 4 ? (int)(total - e) : 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int16_t q[4];
+    if (vec) {
+      const float4 y4 = *reinterpret_cast<const float4 *>(y + e);
+      v[0] = y4.x; v[1] = y4.y; v[2] = y4.z; v[3] = y4.w;
+    } else {
+      for (int j = 0; j < m; ++j) v[j] = y[e + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (int)(((e + (vec ? 0 : j)) / HW) % C);  // (HW % 4 == 0: the four share a channel)
+      const float r = rintf(v[j] - medians[c]);             // round-half-to-even, as torch.round
+      over = over || (j < m && !(r >= -32768.f && r <= 32767.f));
+      q[j] = (int16_t)(int32_t)fminf(fmaxf(r, -32768.f), 32767.f);
+    }
+    if (vec) *reinterpret_cast<short4 *>(sym + e) = make_short4(q[0], q[1], q[2], q[3]);
+    else
+      for (int j = 0; j < m; ++j) sym[e + j] = q[j];
+  }
+  if (over) atomicOr(flag, 1);
+}
+
+// dequantise to fp16 blk16 [B][C16][HW][16]: a block owns 16 channels x 64 positions of one stream - 8-byte reads along
+// the positions, transposed through LDS, 16-byte writes of 8 channels per position
+__global__ __launch_bounds__(256) void eb_dequantize16_blk_kernel(const int16_t *__restrict__ sym, const float *__restrict__ medians,
+                                                                  _Float16 *__restrict__ y_blk, int C, int HW) {
+  __shared__ _Float16 tile[64][16 + 8];
+  const int C16 = (C + 15) / 16;
+  const int p0 = blockIdx.x * 64, c16 = blockIdx.y, b = blockIdx.z;
+  {
+    const int ch = threadIdx.x >> 4, qd = threadIdx.x & 15;
+    const int c = c16 * 16 + ch;
+    short4 q = make_short4(0, 0, 0, 0);
+    float md = 0.f;
+    if (c < C) {
+      q = *reinterpret_cast<const short4 *>(sym + ((size_t)b * C + c) * HW + p0 + 4 * qd);
+      md = medians[c];
+    }
+    tile[4 * qd + 0][ch] = c < C ? (_Float16)((float)q.x + md) : (_Float16)0.f;
+    tile[4 * qd + 1][ch] = c < C ? (_Float16)((float)q.y + md) : (_Float16)0.f;
+    tile[4 * qd + 2][ch] = c < C ? (_Float16)((float)q.z + md) : (_Float16)0.f;
+    tile[4 * qd + 3][ch] = c < C ? (_Float16)((float)q.w + md) : (_Float16)0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int pos = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const uint4 v = *reinterpret_cast<const uint4 *>(&tile[pos][8 * half]);
+    *reinterpret_cast<uint4 *>(y_blk + (((size_t)b * C16 + c16) * HW + p0 + pos) * 16 + 8 * half) = v;
+  }
+}
+
+// ... and to NCHW fp32 (the parity path)
+__global__ __launch_bounds__(256) void eb_dequantize16_nchw_kernel(const int16_t *__restrict__ sym, const float *__restrict__ medians,
+                                                                   float *__restrict__ y, int C, int HW, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    y[e] = (float)sym[e] + medians[(int)((e / HW) % C)];
+}
+
 // What the HOST coder needs of a tile's y stream, in as few bytes as PCIe allows (the host share of a scale-hyperprior
 // call, codec.compress_hyper / decompress_hyper): one word per symbol, table row << 16 | (round(y) & 0xFFFF), for the
 // encoder (`flag` is raised when a symbol does not fit 16 bits: the caller then codes the call on the device); one row
@@ -713,6 +782,35 @@ int licos_gc_build_indexes(const float *scales, const float *table, int levels, 
   hipLaunchKernelGGL(gc_build_indexes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), scales, table, levels,
                      scale_bound, indexes, stride_b, stride_i, n, total);
   LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_symbols16(const float *y, const float *medians, int16_t *symbols, int32_t *flag, int B, int C, int HW, void *stream) {
+  LICOS_REQUIRE(y && medians && symbols && flag && B > 0 && C > 0 && HW > 0, "eb_symbols16: bad arguments");
+  const long total = (long)B * C * HW, quads = (total + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 65536 ? (quads + 255) / 256 : 65536);
+  hipLaunchKernelGGL(eb_symbols16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, medians, symbols, flag, C, HW, total);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int licos_eb_dequantize16(const int16_t *symbols, const float *medians, float *y_nchw, void *y_blk16, int B, int C, int H, int W,
+                          void *stream) {
+  LICOS_REQUIRE(symbols && medians && (y_nchw || y_blk16) && B > 0 && C > 0 && H > 0 && W > 0, "eb_dequantize16: bad arguments");
+  const int HW = H * W;
+  if (y_blk16) {
+    LICOS_REQUIRE(HW % 64 == 0 && B <= 65535 && (C + 15) / 16 <= 65535 && ((uintptr_t)y_blk16 & 15) == 0 && ((uintptr_t)symbols & 7) == 0,
+                  "eb_dequantize16: the blk16 form needs H * W to be a multiple of 64 and aligned buffers");
+    hipLaunchKernelGGL(eb_dequantize16_blk_kernel, dim3(HW / 64, (C + 15) / 16, B), dim3(256), 0, as_stream(stream), symbols, medians,
+                       static_cast<_Float16 *>(y_blk16), C, HW);
+    LICOS_LAUNCH_CHECK();
+  }
+  if (y_nchw) {
+    const long total = (long)B * C * HW;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(eb_dequantize16_nchw_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), symbols, medians, y_nchw, C, HW, total);
+    LICOS_LAUNCH_CHECK();
+  }
   return LICOS_OK;
 }
 

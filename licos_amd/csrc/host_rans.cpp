@@ -118,8 +118,8 @@ long encode_stream(const int32_t *sym, const int32_t *idx, long stride, int n, i
 // K streams in lockstep (same n, same addressing).  The chain of one symbol - table entry, renormalise, reciprocal
 // multiply, add - is ~11 dependent cycles with nothing beside it; K independent chains in one loop body fill the core's
 // issue width (measured: 3.5 -> ~1.2 ns per symbol and thread at K = 4).  Same arithmetic, same bytes as encode_stream.
-template <int K>
-void encode_streams(const int32_t *const (&sym)[K], const int32_t *const (&idx)[K], long stride, int n, int plane, const Tables &t,
+template <int K, typename SymT = int32_t>
+void encode_streams(const SymT *const (&sym)[K], const int32_t *const (&idx)[K], long stride, int n, int plane, const Tables &t,
                     const EncRec *enc, uint32_t *const (&buf)[K], long cap_words, long (&nwords)[K], bool packed = false) {
   WordSink out[K];
   uint64_t x[K];
@@ -184,7 +184,7 @@ void encode_streams(const int32_t *const (&sym)[K], const int32_t *const (&idx)[
         if (__builtin_expect(bad[k], 0)) continue;
         // packed (licos_rans_encode_host_packed): one word per symbol, row << 16 | (symbol & 0xFFFF) - half the bytes
         // over PCIe when the words come from the device (idx[k] == sym[k] then)
-        const int32_t w = sym[k][(long)i * stride];
+        const int32_t w = (int32_t)sym[k][(long)i * stride];
         const int r = packed ? (int)((uint32_t)w >> 16) : idx[k][(long)i * stride];
         if (__builtin_expect((unsigned)r >= (unsigned)t.rows, 0)) { bad[k] = true; continue; }
         const EncRec *e_row = enc + (size_t)r * t.cdf_stride;
@@ -364,8 +364,16 @@ int decode_stream(const uint8_t *data, long nbytes, int32_t *sym, const int32_t 
 
 // K streams in lockstep: see encode_streams.  A decode step is state -> cumulative value -> table search -> multiply ->
 // (rarely) one word in: ~25 dependent cycles alone.
-template <int K, typename IdxT = int32_t>
-void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], int32_t *const (&sym)[K], const IdxT *const (&idx)[K],
+// SymT = int16_t (licos_rans_decode_host_sym16): a decoded value outside 16 bits ends the stream with rc 3 (the caller
+// decodes the batch again into 32-bit symbols).
+template <typename SymT>
+static inline bool put_symbol(SymT *p, int v) {
+  *p = (SymT)v;
+  return sizeof(SymT) >= 4 || v == (int)(SymT)v;
+}
+
+template <int K, typename IdxT = int32_t, typename SymT = int32_t>
+void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], SymT *const (&sym)[K], const IdxT *const (&idx)[K],
                     long stride, int n, int plane, const Tables &t, const DecLut &lut, int (&rc)[K]) {
   WordSource in[K];
   uint64_t x[K];
@@ -428,7 +436,11 @@ void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], in
             const int v = (int)(raw >> 1);
             value = (raw & 1) ? -v - 1 : v + maxv;
           }
-          sym[k][(long)i * stride] = value + o;
+          if (__builtin_expect(!put_symbol(&sym[k][(long)i * stride], value + o), 0)) {
+            rc[k] = 3;
+            done[k] = true;
+            stop = true;
+          }
           if (__builtin_expect(in[k].overrun, 0)) {  // finish this stream here; the others continue in the general loop
             for (int j = i + 1; j < n; ++j) sym[k][(long)j * stride] = 0;
             rc[k] = 1;
@@ -476,7 +488,7 @@ void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], in
           const int v = (int)(raw >> 1);
           value = (raw & 1) ? -v - 1 : v + maxv;
         }
-        sym[k][(long)i * stride] = value + o;
+        if (__builtin_expect(!put_symbol(&sym[k][(long)i * stride], value + o), 0)) { rc[k] = 3; done[k] = true; }
         if (__builtin_expect(in[k].overrun, 0)) {
           for (int j = i + 1; j < n; ++j) sym[k][(long)j * stride] = 0;
           rc[k] = 1;
@@ -532,7 +544,7 @@ void decode_streams(const uint8_t *const (&data)[K], const long (&nbytes)[K], in
         const int v = (int)(raw >> 1);
         value = (raw & 1) ? -v - 1 : v + max_value[k];
       }
-      sym[k][(long)i * stride] = value + off[k];
+      if (__builtin_expect(!put_symbol(&sym[k][(long)i * stride], value + off[k]), 0)) { rc[k] = 3; done[k] = true; }
       if (__builtin_expect(in[k].overrun, 0)) {
         for (int j = i + 1; j < n; ++j) sym[k][(long)j * stride] = 0;
         rc[k] = 1;
@@ -630,7 +642,8 @@ inline int lockstep_width(int batch, int nthreads) {
 
 using namespace licos;
 
-static int encode_host(const int32_t *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
+template <typename SymT>
+static int encode_host(const SymT *symbols, const int32_t *indexes, long sym_stride_b, long sym_stride_i, int n,
                        int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
                        int rows, const void *enc_table, uint8_t *out, long cap_bytes_per_stream, int64_t *nbytes,
                        int batch, int nthreads, bool packed) {
@@ -658,7 +671,8 @@ static int encode_host(const int32_t *symbols, const int32_t *indexes, long sym_
   const int njobs = (batch + K - 1) / K;
   auto run_group = [&](auto kc, int b0) {
     constexpr int KK = decltype(kc)::value;
-    const int32_t *sp[KK], *ip[KK];
+    const SymT *sp[KK];
+    const int32_t *ip[KK];
     uint32_t *bp[KK];
     long nw[KK];
     for (int k = 0; k < KK; ++k) {
@@ -666,16 +680,16 @@ static int encode_host(const int32_t *symbols, const int32_t *indexes, long sym_
       ip[k] = indexes ? indexes + (size_t)(b0 + k) * sym_stride_b : nullptr;
       bp[k] = reinterpret_cast<uint32_t *>(out + (size_t)(b0 + k) * cap_bytes_per_stream);
     }
-    encode_streams<KK>(sp, ip, sym_stride_i, n, plane, t, enc, bp, cap_words, nw, packed);
+    encode_streams<KK, SymT>(sp, ip, sym_stride_i, n, plane, t, enc, bp, cap_words, nw, packed);
     for (int k = 0; k < KK; ++k) finish(b0 + k, nw[k]);
   };
   Pool::instance().run(njobs, nthreads, [&](int j) {
     const int b0 = j * K, cnt = batch - b0 < K ? batch - b0 : K;
     if (cnt == 4) run_group(std::integral_constant<int, 4>{}, b0);
     else if (cnt == 2) run_group(std::integral_constant<int, 2>{}, b0);
-    else if (packed)
+    else if (packed || !std::is_same<SymT, int32_t>::value)
       for (int k = 0; k < cnt; ++k) run_group(std::integral_constant<int, 1>{}, b0 + k);
-    else
+    else if constexpr (std::is_same<SymT, int32_t>::value)
       for (int k = 0; k < cnt; ++k) {
         uint32_t *buf = reinterpret_cast<uint32_t *>(out + (size_t)(b0 + k) * cap_bytes_per_stream);
         finish(b0 + k, encode_stream(symbols + (size_t)(b0 + k) * sym_stride_b, indexes ? indexes + (size_t)(b0 + k) * sym_stride_b : nullptr,
@@ -687,10 +701,10 @@ static int encode_host(const int32_t *symbols, const int32_t *indexes, long sym_
   return LICOS_OK;
 }
 
-template <typename IdxT>
+template <typename IdxT, typename SymT = int32_t>
 static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *indexes, long sym_stride_b,
                        long sym_stride_i, int n, int plane, const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
-                       const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int batch, int nthreads) {
+                       const int32_t *offset, int rows, SymT *symbols, int32_t *status, int batch, int nthreads) {
   LICOS_REQUIRE(in && byte_off && cdf && cdf_len && offset && symbols && status, "rans_decode_host: NULL buffer");
   LICOS_REQUIRE(n >= 0 && batch >= 0 && rows > 0 && cdf_stride > 1, "rans_decode_host: bad shape");
   LICOS_REQUIRE(indexes || plane > 0, "rans_decode_host: plane must be positive without explicit indexes");
@@ -701,7 +715,7 @@ static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *i
   lut.build(t);
   std::atomic<int> worst{0};
   auto note = [&](int rc) {
-    if (rc < 0) rc = 2;
+    if (rc < 0) rc = 4;  // (above 3 = "a symbol outside 16 bits": an error wins over it)
     int prev = worst.load();
     while (rc > prev && !worst.compare_exchange_weak(prev, rc)) {}
   };
@@ -709,17 +723,17 @@ static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *i
   const int njobs = (batch + K - 1) / K;
   auto one = [&](int b) {
     const long nb = (long)(byte_off[b + 1] - byte_off[b]);
-    if (nb < 0) return note(2);
-    if constexpr (std::is_same<IdxT, int32_t>::value) {
+    if (nb < 0) return note(4);
+    if constexpr (std::is_same<IdxT, int32_t>::value && std::is_same<SymT, int32_t>::value) {
       note(decode_stream(in + byte_off[b], nb, symbols + (size_t)b * sym_stride_b,
                          indexes ? indexes + (size_t)b * sym_stride_b : nullptr, sym_stride_i, n, plane, t, lut));
     } else {
       const uint8_t *dp[1] = {in + byte_off[b]};
       const long nbs[1] = {nb};
-      int32_t *sp[1] = {symbols + (size_t)b * sym_stride_b};
+      SymT *sp[1] = {symbols + (size_t)b * sym_stride_b};
       const IdxT *ip[1] = {indexes ? indexes + (size_t)b * sym_stride_b : nullptr};
       int rc[1];
-      decode_streams<1, IdxT>(dp, nbs, sp, ip, sym_stride_i, n, plane, t, lut, rc);
+      decode_streams<1, IdxT, SymT>(dp, nbs, sp, ip, sym_stride_i, n, plane, t, lut, rc);
       note(rc[0]);
     }
   };
@@ -727,7 +741,7 @@ static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *i
     constexpr int KK = decltype(kc)::value;
     const uint8_t *dp[KK];
     long nb[KK];
-    int32_t *sp[KK];
+    SymT *sp[KK];
     const IdxT *ip[KK];
     int rc[KK];
     for (int k = 0; k < KK; ++k) {
@@ -740,7 +754,7 @@ static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *i
       sp[k] = symbols + (size_t)(b0 + k) * sym_stride_b;
       ip[k] = indexes ? indexes + (size_t)(b0 + k) * sym_stride_b : nullptr;
     }
-    decode_streams<KK, IdxT>(dp, nb, sp, ip, sym_stride_i, n, plane, t, lut, rc);
+    decode_streams<KK, IdxT, SymT>(dp, nb, sp, ip, sym_stride_i, n, plane, t, lut, rc);
     for (int k = 0; k < KK; ++k) note(rc[k]);
   };
   Pool::instance().run(njobs, nthreads, [&](int j) {
@@ -750,8 +764,8 @@ static int decode_host(const uint8_t *in, const int64_t *byte_off, const IdxT *i
     else
       for (int k = 0; k < cnt; ++k) one(b0 + k);
   });
-  if (worst.load() == 2) return fail(LICOS_EINVAL, "rans_decode_host: CDF row out of range or bad stream offsets");
-  status[0] = worst.load();  // 1: some stream ended before all its symbols were decoded
+  if (worst.load() == 4) return fail(LICOS_EINVAL, "rans_decode_host: CDF row out of range or bad stream offsets");
+  status[0] = worst.load();  // 1: some stream ended before all its symbols were decoded; 3 (16-bit symbols): a value did not fit
   return LICOS_OK;
 }
 
@@ -777,6 +791,22 @@ int licos_rans_decode_host(const uint8_t *in, const int64_t *byte_off, const int
                            const int32_t *offset, int rows, int32_t *symbols, int32_t *status, int batch, int nthreads) {
   return decode_host<int32_t>(in, byte_off, indexes, sym_stride_b, sym_stride_i, n, plane, cdf, cdf_stride, cdf_len, offset, rows,
                               symbols, status, batch, nthreads);
+}
+
+int licos_rans_encode_host_sym16(const int16_t *symbols, long stride_b, int n, int plane, const int32_t *cdf, int cdf_stride,
+                                 const int32_t *cdf_len, const int32_t *offset, int rows, const void *enc_table, uint8_t *out,
+                                 long cap_bytes_per_stream, int64_t *nbytes, int batch, int nthreads) {
+  LICOS_REQUIRE(plane > 0, "rans_encode_host_sym16: channel-plane rows only");
+  return encode_host<int16_t>(symbols, nullptr, stride_b, 1, n, plane, cdf, cdf_stride, cdf_len, offset, rows, enc_table, out,
+                              cap_bytes_per_stream, nbytes, batch, nthreads, false);
+}
+
+int licos_rans_decode_host_sym16(const uint8_t *in, const int64_t *byte_off, long stride_b, int n, int plane, const int32_t *cdf,
+                                 int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int rows, int16_t *symbols,
+                                 int32_t *status, int batch, int nthreads) {
+  LICOS_REQUIRE(plane > 0, "rans_decode_host_sym16: channel-plane rows only");
+  return decode_host<int32_t, int16_t>(in, byte_off, static_cast<const int32_t *>(nullptr), stride_b, 1, n, plane, cdf, cdf_stride,
+                                       cdf_len, offset, rows, symbols, status, batch, nthreads);
 }
 
 int licos_rans_decode_host_rows8(const uint8_t *in, const int64_t *byte_off, const uint8_t *rows8, long stride_b, int n,

@@ -584,6 +584,26 @@ def eb_dequantize(symbols, sym_stride_b, sym_stride_i, medians, b, c, h, w, want
     return y
 
 
+def eb_symbols16(y, medians, symbols16, flag):
+    """symbols16 int16 [B][n] (device) = round(y - median[channel]); flag int32 [1] (device) |= 1 on a symbol outside
+    int16 - what the host coder's 16-bit form reads (rans_encode_host_sym16)."""
+    _dev(y, medians, symbols16, flag)
+    b, c = y.shape[:2]
+    hw = y[0, 0].numel()
+    rc = _lib.load().licos_eb_symbols16(_p(_f32(y)), _p(_f32(medians)), _p(symbols16), _p(flag), b, c, hw, _stream())
+    _lib.check(rc, "eb_symbols16")
+    return symbols16
+
+
+def eb_dequantize16(symbols16, medians, b, c, h, w, want_nchw=True, blk16=None):
+    """y_hat of int16 symbols [B][n] (device): NCHW fp32 (returned) and / or fp16 blk16 (written into `blk16`)."""
+    _dev(symbols16, medians, blk16)
+    y = torch.empty((b, c, h, w), device=medians.device, dtype=torch.float32) if want_nchw else None
+    rc = _lib.load().licos_eb_dequantize16(_p(symbols16), _p(medians), _p(y), _p(blk16), b, c, h, w, _stream())
+    _lib.check(rc, "eb_dequantize16")
+    return y
+
+
 def reduce_sqdiff(a, b, clamp01=False):
     _dev(a, b)
     out = torch.zeros(1, device=a.device, dtype=torch.float64)
@@ -868,6 +888,46 @@ def rans_encode_host_packed(packed, n, cdf, cdf_len, offset, enc_table, nthreads
         cap = 8 * n + 16  # worst case: under two words per symbol
     _lib.check(rc, "rans_encode_host_packed")
     return out, nbytes
+
+
+def rans_encode_host_sym16(symbols16, n, plane, cdf, cdf_len, offset, enc_table, nthreads=None):
+    """Host coder on 16-bit symbols, channel-plane rows: int16 numpy [B][n].  Returns (out uint8 [B][cap], nbytes int64 [B])."""
+    sym = np.ascontiguousarray(symbols16, dtype=np.int16)
+    b = sym.shape[0]
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    cap = 4 * (n // 2 + 64)
+    for attempt in range(2):
+        out = np.empty((b, cap), dtype=np.uint8)
+        nbytes = np.zeros(b, dtype=np.int64)
+        rc = _lib.load().licos_rans_encode_host_sym16(ctypes.c_void_p(sym.ctypes.data), n, n, plane, cp, cdf_a.shape[1], lp, op,
+                                                      cdf_a.shape[0], ctypes.c_void_p(enc_table.ctypes.data),
+                                                      ctypes.c_void_p(out.ctypes.data), cap, ctypes.c_void_p(nbytes.ctypes.data), b, nthreads)
+        if rc != -4 or attempt == 1:
+            break
+        cap = 8 * n + 16  # worst case: under two words per symbol
+    _lib.check(rc, "rans_encode_host_sym16")
+    return out, nbytes
+
+
+def rans_decode_host_sym16(data, byte_off, n, plane, cdf, cdf_len, offset, batch, out, nthreads=None):
+    """Host decoder into 16-bit symbols (int16 numpy [B][n], channel-plane rows).  Returns the status: 1 a stream ended
+    early, 3 a value does not fit int16 (decode again with rans_decode_host)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off64 = np.ascontiguousarray(byte_off, dtype=np.int64)
+    cdf_a, cp = _np_i32(cdf)
+    len_a, lp = _np_i32(cdf_len)
+    off_a, op = _np_i32(offset)
+    status = np.zeros(1, dtype=np.int32)
+    nthreads = host_threads() if nthreads is None else int(nthreads)
+    assert out.dtype == np.int16 and out.flags["C_CONTIGUOUS"] and out.shape == (batch, n)
+    rc = _lib.load().licos_rans_decode_host_sym16(ctypes.c_void_p(data.ctypes.data), ctypes.c_void_p(off64.ctypes.data), n, n, plane, cp,
+                                                  cdf_a.shape[1], lp, op, cdf_a.shape[0], ctypes.c_void_p(out.ctypes.data),
+                                                  ctypes.c_void_p(status.ctypes.data), batch, nthreads)
+    _lib.check(rc, "rans_decode_host_sym16")
+    return int(status[0])
 
 
 def rans_decode_host_rows8(data, byte_off, rows8, n, cdf, cdf_len, offset, batch, out, nthreads=None):

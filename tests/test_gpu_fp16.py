@@ -855,3 +855,53 @@ def test_dequantise_to_blk16_layouts_agree(b, c, h, w):
         assert float(full[:, c:].abs().max()) == 0.0 or (h * w) % 16 != 0
     want = sym.t().reshape(b, c, h, w).float() + med.view(1, c, 1, 1)
     assert torch.equal(ref, want)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+def test_host_tiles_as_16_bit_symbols(monkeypatch, precision):
+    """The host's tiles cross PCIe as 16-bit symbols (codec.SYM16: licos_eb_symbols16 / licos_eb_dequantize16 and the
+    host coder's 16-bit entries): the strings and tiles of the 32-bit form; latents beyond 16 bits make compress fall back
+    to it for the call and decompress for the sub-chunk concerned."""
+    from licos_amd import codec
+    monkeypatch.setattr(ops, "HOST_CODER", "1")
+    monkeypatch.setattr(ops, "host_threads", lambda: 2)
+    monkeypatch.setattr(codec, "HOST_SUB", 2)  # sub-chunks of 4 tiles
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=6, y_gain=20.0)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision(precision)
+    net.update(force=True)
+    x = om.synthetic_tiles(22, 3, 128, seed=34).to(DEV)  # 8 x 8 latents: the blk16 form of the 16-bit dequantise applies
+    calls = {"enc16": 0, "dec16": 0, "dec32": 0}
+    for name, key in (("rans_encode_host_sym16", "enc16"), ("rans_decode_host_sym16", "dec16"), ("rans_decode_host", "dec32")):
+        real = getattr(ops, name)
+        monkeypatch.setattr(ops, name, lambda *a, _r=real, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _r(*a, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setattr(codec, "SYM16", False)
+        c0 = net.compress(x)
+        ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
+        assert calls["enc16"] == 0 and calls["dec16"] == 0 and calls["dec32"] > 0
+        monkeypatch.setattr(codec, "SYM16", True)
+        calls["dec32"] = 0
+        c = net.compress(x)
+        got = net.decompress(c["strings"], c["shape"])["x_hat"]
+        assert calls["enc16"] > 0 and calls["dec16"] > 0 and calls["dec32"] == 0
+        assert [bytes(s_) for s_ in c["strings"][0]] == [bytes(s_) for s_ in c0["strings"][0]]
+        assert torch.equal(got, ref)
+        # latents up to +-10^5: compress finds the flag of a sub-chunk raised and codes the call with 32-bit symbols; decompress
+        # decodes the sub-chunks concerned twice (16-bit attempt, then 32-bit)
+        ymax = float(net.g_a(x).abs().max())
+        net.g_a[6].weight.mul_(1.0e5 / ymax)
+        net.g_a[6].bias.mul_(1.0e5 / ymax)
+        assert float(net.g_a(x).abs().max()) > 5.0e4
+        monkeypatch.setattr(codec, "SYM16", False)
+        b0 = net.compress(x)
+        bref = net.decompress(b0["strings"], b0["shape"])["x_hat"]
+        monkeypatch.setattr(codec, "SYM16", True)
+        calls.update(enc16=0, dec16=0, dec32=0)
+        b1 = net.compress(x)
+        assert [bytes(s_) for s_ in b1["strings"][0]] == [bytes(s_) for s_ in b0["strings"][0]]
+        assert max(len(s_) for s_ in b1["strings"][0]) > 3 * max(len(s_) for s_ in c["strings"][0])
+        bgot = net.decompress(b1["strings"], b1["shape"])["x_hat"]
+        assert calls["dec16"] > 0 and 1 <= calls["dec32"] <= calls["dec16"]
+        assert torch.allclose(bgot, bref, rtol=0, atol=0, equal_nan=True)  # (latents this large overflow the synthesis)

@@ -143,3 +143,38 @@ def test_host_coder_compact_forms_equal_the_oracle(batch, threads):
     bad[0, 5] = (200 << 16) | 3
     with pytest.raises(Exception):
         ops.rans_encode_host_packed(bad, n, cdf, cl, off, table, nthreads=threads)
+
+
+@pytest.mark.parametrize("batch,threads", [(1, 1), (6, 3), (21, 8)])
+def test_host_coder_16_bit_symbols_equal_the_oracle(batch, threads):
+    """licos_rans_encode_host_sym16 / licos_rans_decode_host_sym16 (channel-plane rows, int16 symbols: what the factorized
+    codec's host share moves over PCIe): the oracle's bytes and symbols, escapes to the 16-bit ends; a stream whose values
+    do not fit int16 is reported (status 3), not truncated."""
+    cdf, cl, off, table = _tables(seed=10 + batch)
+    rng = np.random.default_rng(batch)
+    c, plane = 192, 16
+    n = c * plane
+    sym = np.rint(rng.standard_normal((batch, n)) * 9).astype(np.int32)
+    sym[0, 3], sym[0, 8], sym[-1, n - 1] = 32767, -32768, -3000
+    idx = np.repeat(np.arange(c, dtype=np.int32), plane)
+    out, nb = ops.rans_encode_host_sym16(sym.astype(np.int16), n, plane, cdf, cl, off, table, nthreads=threads)
+    got = _strings(out, nb)
+    assert got == [rans.encode_with_indexes(sym[b], idx, cdf, cl, off) for b in range(batch)]
+    data = np.frombuffer(b"".join(got), dtype=np.uint8)
+    byte_off = np.concatenate(([0], np.cumsum(nb))).astype(np.int64)
+    dec = np.full((batch, n), -7, dtype=np.int16)
+    assert ops.rans_decode_host_sym16(data, byte_off, n, plane, cdf, cl, off, batch, out=dec, nthreads=threads) == 0
+    assert np.array_equal(dec.astype(np.int32), sym)
+    # a value beyond 16 bits in the last stream: status 3 from the 16-bit decoder, the 32-bit one returns it
+    big = sym.copy()
+    big[-1, 40] = 40000
+    o2, n2 = ops.rans_encode_host(big, n, plane, cdf, cl, off, table, nthreads=threads)
+    d2 = np.frombuffer(b"".join(_strings(o2, n2)), dtype=np.uint8)
+    bo2 = np.concatenate(([0], np.cumsum(n2))).astype(np.int64)
+    assert ops.rans_decode_host_sym16(d2, bo2, n, plane, cdf, cl, off, batch, out=dec, nthreads=threads) == 3
+    full, st = ops.rans_decode_host(d2, bo2, n, plane, cdf, cl, off, batch, nthreads=threads)
+    assert st == 0 and np.array_equal(full, big)
+    # a truncated stream
+    cut = byte_off.copy()
+    cut[-1] -= 8
+    assert ops.rans_decode_host_sym16(data[: cut[-1]], cut, n, plane, cdf, cl, off, batch, out=dec, nthreads=threads) == 1

@@ -154,9 +154,22 @@ def _note_host_rate(direction, tiles, nsym, seconds, expect_ns=None):
     _host_factor[direction] = 0.5 * _host_factor[direction] + 0.5 * f
 
 
+_cap_state = {}
+
+
 def host_capacity(direction):
-    """Tiles the host cores code in the time of ONE device coder launch (independent of the stream length)."""
-    return max(0, int(0.85 * ops.host_threads() * DEV_NS[direction] / (HOST_NS[direction] * _host_factor[direction])))
+    """Tiles the host cores code in the time of ONE device coder launch (independent of the stream length), on a grid of
+    2 tiles per thread and with one grid step of hysteresis: the measured host rate moves a little with every call, and
+    a share that moved with it would give every call its own tensor shapes (3 751, 3 775, 3 747 ... tiles in a piece) -
+    work for the caching allocator, and now and then a hipMalloc in the middle of a step."""
+    threads = ops.host_threads()
+    raw = 0.85 * threads * DEV_NS[direction] / (HOST_NS[direction] * _host_factor[direction])
+    grid = 2 * threads
+    key = (direction, threads)
+    last = _cap_state.get(key)
+    if last is None or abs(raw - (last + 0.5 * grid)) >= grid:
+        last = _cap_state[key] = max(0, int(raw) // grid * grid if raw >= grid else int(raw))
+    return last
 
 
 def host_share(batch, direction):

@@ -155,6 +155,7 @@ def _note_host_rate(direction, tiles, nsym, seconds, expect_ns=None):
 
 
 _cap_state = {}
+ENC_TAIL = float(os.environ.get("LICOS_ENC_TAIL_FRACTION", "1.0"))  # share of the capacity at the end of a larger compress call
 
 
 def host_capacity(direction):
@@ -176,9 +177,8 @@ def host_share(batch, direction):
     """How many tiles of a call of `batch` tiles the host codes.  Everything up to the host's capacity for the direction
     (a thousand tiles encoding, four hundred decoding at 16 threads: the device coder's launch latency alone is longer
     than the host takes).  Of a larger call, the tiles at its exposed end: the first `capacity` tiles of a decode - the
-    synthesis transform starts on them while the first device launch runs - and the last 0.7 x `capacity` of an encode
-    (the host pipeline moves ~100 tiles per ms: what it finishes beside the last 7-ms device launch and that launch's
-    drain).  `capacity` follows the rate the host coder delivered in this process's recent calls (_note_host_rate).
+    synthesis transform starts on them while the first device launch runs - and the last `capacity` tiles of an encode
+    (what the host pipeline finishes beside the last 7-ms device launch and that launch's drain; ENC_TAIL scales it).  `capacity` follows the rate the host coder delivered in this process's recent calls (_note_host_rate).
     The large-call split was measured and left out twice earlier in round 4 (+10 ms per 16 384-tile step); the loss was
     not the split: a piece of decompress that joins a packed segment with the tiles the host encoded built its end offset
     with `torch.tensor([n], device=...)`, a blocking copy that waited for every decode launch queued so far (fixed:
@@ -193,7 +193,7 @@ def host_share(batch, direction):
     cap = host_capacity(direction)
     if batch <= cap:
         return batch
-    return cap if direction == "dec" else int(0.7 * cap)
+    return cap if direction == "dec" else int(ENC_TAIL * cap)
 
 
 _pinned = {}

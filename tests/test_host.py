@@ -418,8 +418,8 @@ def test_host_share_of_a_call(monkeypatch):
     for b in (1, 16, 64, 384):
         assert codec.host_share(b, "enc") == b and codec.host_share(b, "dec") == b  # the host-only batches of rounds 2 - 3
     assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(cap_d + 1, "dec") == cap_d  # split: the call's first tiles
-    assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(cap_e + 1, "enc") == int(0.7 * cap_e)  # ... its last
-    assert codec.host_share(16384, "enc") == int(0.7 * cap_e) and codec.host_share(16384, "dec") == cap_d  # the exposed ends
+    assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(cap_e + 1, "enc") == int(codec.ENC_TAIL * cap_e)  # ... its last
+    assert codec.host_share(16384, "enc") == int(codec.ENC_TAIL * cap_e) and codec.host_share(16384, "dec") == cap_d  # the exposed ends
     monkeypatch.setattr(codec, "HOST_SPLIT", False)
     assert codec.host_share(1000, "enc") == 0 and codec.host_share(64, "enc") == 64
     monkeypatch.setattr(ops, "HOST_CODER", "0")

@@ -134,7 +134,8 @@ SYM16 = os.environ.get("LICOS_SYM16", "1") != "0"
 
 
 def _pinned_i16(role, rows, cols):
-    return _pinned_i32(role, rows, (cols + 1) // 2).view(torch.int16)[:, :cols]
+    """A reusable page-locked int16 [rows, cols] staging area (contiguous whatever the parity of cols)."""
+    return _pinned_i32(role, 1, (rows * cols + 1) // 2).view(torch.int16)[0, :rows * cols].view(rows, cols)
 
 
 # Feedback: what the host coder actually delivered in this process's recent calls, as a factor on HOST_NS (1 = nominal).
@@ -706,10 +707,18 @@ def compress_hyper(net, x, chunk=512, cap_words=None, host=True):
         rec, aux = ops.gc_encode_prepare(y.contiguous(), scales.contiguous(), gc.scale_table, bound, ytab, ylen, yoff, ycdf.shape[1])
         ready = torch.cuda.Event()
         ready.record(main)
+        # (the z coder's 1.7 ms on a stream of its own: in front of the y coder on ONE stream it lengthened the exposed end of
+        # the call by as much)
+        zside = _stream(dev, "coder%d" % ((ci + 1) % CODER_STREAMS))  # (the neighbour chunk's: no further hardware queue)
+        with torch.cuda.stream(zside):
+            zside.wait_event(ready)
+            zpart = _timed_coder("z_encode", lambda: ops.rans_encode_batch(zsym, 1, n, nz, zplane, zcdf, zlen, zoff, ztab, zcap, n))
+            zcoded = torch.cuda.Event()
+            zcoded.record(zside)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            zpart = _timed_coder("z_encode", lambda: ops.rans_encode_batch(zsym, 1, n, nz, zplane, zcdf, zlen, zoff, ztab, zcap, n))
             ypart = _timed_coder("y_encode", lambda: ops.rans_encode_records(rec, aux, ycap))
+            side.wait_event(zcoded)
             coded = torch.cuda.Event()
             coded.record(side)
         queued.append((s0, n, (y, z, zsym, rec, aux), ypart, zpart, coded))
@@ -818,7 +827,7 @@ def compress_hyper(net, x, chunk=512, cap_words=None, host=True):
             raise RuntimeError("licos_amd: rANS scratch overflow at worst-case capacity")
         del queued
         return compress_hyper(net, x, chunk=hyper_retry_chunk(chunk, ny), cap_words=2 * ny + 8)
-    for ci in range(min(CODER_STREAMS, len(segments))):
+    for ci in range(min(CODER_STREAMS, len(segments) + 1)):
         main.wait_stream(_stream(dev, "coder%d" % ci))
     main.wait_stream(copy)
     main.wait_stream(hcopy)

@@ -7,7 +7,7 @@ from licos_amd import checkpoint, synthetic
 dev = torch.device("cuda:0")
 net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(dev).eval().set_precision("fp16")
 checkpoint.load_checkpoint(os.path.join(os.path.dirname(licos_amd.__file__), "weights", "factorized_q3_c3.pth.tar"), net)
-net.chunk = 4096
+net.chunk = int(os.environ.get("PROBE_CHUNK", "4096"))
 sizes = [int(a) for a in sys.argv[1:]] or [16, 64, 256, 1024]
 x = synthetic.tiles(max(sizes), 3, 256, seed=5, kind="aid", device=dev)
 with torch.no_grad():

@@ -641,7 +641,7 @@ def hyper_host_share(batch, direction="enc"):
     host threads code during the ONE device launch of the y coder that is exposed per call (31 ms encoding, 23 ms
     decoding a 512^2 tile's 196 608 symbols) - their transforms then run beside that launch instead of in front of /
     behind it.  A scale-hyperprior tile is 37 us of transforms on the encode side and the host codes it in 59 us
-    (16 threads), so - unlike the factorized codec's large calls, section "split placement" above - the host keeps up
+    (16 threads), so the host keeps up
     with the device for the length of that launch.  The count moves in steps of 4 x threads and only when the measured host
     rate has moved it by a whole step (a change of the device chunks' sizes costs the caching allocator a round of
     hipMalloc, 30 ms)."""

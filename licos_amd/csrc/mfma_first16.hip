@@ -157,7 +157,10 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_kernel(First16Args a
   _Float16 *y_img = a.y_blk + (size_t)b * Cout16 * a.Ho * a.Wo * 16;
   // (Measured and not kept: the counted wait of mfma_first.hip around the epilogue - the next tile's second weight row
   // requested before the stores, no raw rows in the first step, s_waitcnt vmcnt(16) behind it: 22.3 against 22.0 ms per
-  // 2048 tiles of 13 x 512^2.  Every step ends with vmcnt(0).)
+  // 2048 tiles of 13 x 512^2.  Every step ends with vmcnt(0).  Second half of round 4, also not kept: one-dword "touches" of
+  // the 128-byte lines of the rows two steps ahead (compiler-visible loads summed into a dead register, the step's wait
+  // leaving them in flight) so that the rows come from L2: 24.6 - 25.1 against 21.7 ms - the kernel is at its register
+  // limit (255 VGPRs and 4 spills with the touch's address arithmetic) and the extra requests queue in front of the rows.)
   int wcur = 0;
   for (int t = 0; t < t_count; ++t) {
     const int tile = t_first + t;

@@ -301,6 +301,8 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
         if drain(qi):
             overflow = True
             break
+    if host_trace is not None:
+        host_trace.append(("enc-drained", len(queued) - 1, time.perf_counter()))
     # The host's tiles, a software pipeline in this thread: queue sub-chunk k's transforms + quantise (main stream) and
     # the copy of its symbols [stream][position] to a page-locked buffer (a stream of its own), THEN code sub-chunk k - 1
     # while the GPU works on k.  (Queueing everything first and coding afterwards cost a 1024-tile call 4.5 ms: a
@@ -329,7 +331,7 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
             _note_host_rate("enc", m, nsym, w2 - w1)
             strings[n_dev + t0:n_dev + t0 + m] = [out[i, : int(nbytes[i])].tobytes() for i in range(m)]
             if host_trace is not None:
-                host_trace.append(("enc", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
+                host_trace.append(("enc", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3), w0))
 
         pending = None
         try:
@@ -376,8 +378,12 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
         except BaseException:
             torch.cuda.synchronize(dev)  # later sub-chunks' copies still target the shared page-locked buffer: let them land
             raise
+    if host_trace is not None:
+        host_trace.append(("enc-host-done", n_host, time.perf_counter()))
     if queued and not overflow:
         overflow = drain(len(queued) - 1)
+    if host_trace is not None:
+        host_trace.append(("enc-last-drained", 0, time.perf_counter()))
     if overflow:
         torch.cuda.synchronize(dev)
         if cap_words >= 2 * nsym + 8:

@@ -131,6 +131,7 @@ ZERO_COPY = os.environ.get("LICOS_ZERO_COPY", "0") == "1"
 # of that.  A symbol outside 16 bits is flagged by the quantise kernel / the host decoder and the call (the sub-chunk)
 # falls back to the 32-bit form.  LICOS_SYM16=0 switches it off (A/B).
 SYM16 = os.environ.get("LICOS_SYM16", "1") != "0"
+PREQUEUE = int(os.environ.get("LICOS_PREQUEUE", "3"))  # host sub-chunks of a large compress queued before the drains (0: none; A/B)
 
 
 def _pinned_i16(role, rows, cols):
@@ -296,6 +297,51 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
         segments.append((s0, n, host_t, off))
         return False
 
+    # The host's first sub-chunks are queued BEFORE the device chunks are drained: a drain is milliseconds of this thread
+    # (lengths, compaction, D2H, 4096 bytes objects), and with nothing queued behind the last device chunk's transforms the
+    # GPU idled ~2 ms at the very place the call is exposed (tools/tail_probe.py).
+    subs = list(_ramp(n_host, 2 * ops.host_threads(), max(1, HOST_SUB * ops.host_threads()))) if n_host else []
+    host_state = {"stage": None}
+    use16 = (SYM16 if sym16 is None else sym16) and not ZERO_COPY
+    hflag = torch.zeros(max(1, len(subs)), device=dev, dtype=torch.int32) if use16 else None
+    st_f = _pinned_i32("ef", 1, max(64, len(subs)))[0] if use16 else None
+
+    def queue_sub(k):
+        """Sub-chunk k of the host's tiles: transforms + quantise on the main stream, symbols to the page-locked buffer."""
+        nonlocal shape, nsym, plane
+        (t0, m) = subs[k]
+        y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
+        if shape is None:
+            shape = tuple(y.shape[-2:])
+            nsym, plane = y[0].numel(), y[0, 0].numel()
+        if host_state["stage"] is None:
+            host_state["stage"] = _pinned_i16("enc16", n_host, nsym) if use16 else _pinned_i32("enc", n_host, nsym)
+        stage = host_state["stage"]
+        if ZERO_COPY:
+            ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
+            landed = torch.cuda.Event()
+            landed.record(main)
+            return (k, t0, m, y, landed)
+        if use16:
+            hsym = torch.empty((m, nsym), device=dev, dtype=torch.int16)
+            ops.eb_symbols16(y.contiguous(), med, hsym, hflag[k:k + 1])
+        else:
+            hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
+            ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        # (a stream of its own: on the drains' copy stream these copies would queue up behind / in front of the device
+        # chunks' length and byte transfers)
+        with torch.cuda.stream(hcopy):
+            hcopy.wait_event(ready)
+            stage[t0:t0 + m].copy_(hsym, non_blocking=True)
+            if use16:
+                st_f[k:k + 1].copy_(hflag[k:k + 1], non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(hcopy)
+        return (k, t0, m, hsym, landed)
+
+    prequeued = [queue_sub(k) for k in range(min(PREQUEUE, len(subs)))] if len(queued) > 1 else []
     # every device chunk but the last (the last device launch runs beside the host's share below)
     for qi in range(len(queued) - 1):
         if drain(qi):
@@ -309,18 +355,13 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
     # sub-chunk's ten launches are ~0.6 ms of Python, during which the host coder had nothing to do.)
     if n_host and not overflow:
         hcdf, hlen, hoff, htable = eb.coder_tables_host()
-        sub = max(1, HOST_SUB * ops.host_threads())
-        subs = list(_ramp(n_host, 2 * ops.host_threads(), sub))
-        stage = None
-        use16 = (SYM16 if sym16 is None else sym16) and not ZERO_COPY
-        hflag = torch.zeros(len(subs), device=dev, dtype=torch.int32) if use16 else None
-        st_f = _pinned_i32("ef", 1, max(64, len(subs)))[0] if use16 else None
 
         def host_encode(entry):
             (k, t0, m, _keep, landed) = entry
             w0 = time.perf_counter()
             landed.synchronize()
             w1 = time.perf_counter()
+            stage = host_state["stage"]
             if use16:
                 if int(st_f[k]) != 0:
                     raise _HostRange()
@@ -333,44 +374,15 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
             if host_trace is not None:
                 host_trace.append(("enc", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3), w0))
 
-        pending = None
         try:
-            for k, (t0, m) in enumerate(subs):
-                y = net.g_a(x[n_dev + t0:n_dev + t0 + m])
-                if shape is None:
-                    shape = tuple(y.shape[-2:])
-                    nsym, plane = y[0].numel(), y[0, 0].numel()
-                if stage is None:
-                    stage = _pinned_i16("enc16", n_host, nsym) if use16 else _pinned_i32("enc", n_host, nsym)
-                if ZERO_COPY:
-                    ops.eb_quantize(y.contiguous(), med, "symbols", symbols=stage[t0:t0 + m], sym_stride_b=nsym, sym_stride_i=1)
-                    landed = torch.cuda.Event()
-                    landed.record(main)
-                    entry = (k, t0, m, y, landed)
-                else:
-                    if use16:
-                        hsym = torch.empty((m, nsym), device=dev, dtype=torch.int16)
-                        ops.eb_symbols16(y.contiguous(), med, hsym, hflag[k:k + 1])
-                    else:
-                        hsym = torch.empty((m, nsym), device=dev, dtype=torch.int32)
-                        ops.eb_quantize(y.contiguous(), med, "symbols", symbols=hsym, sym_stride_b=nsym, sym_stride_i=1)
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    # (a stream of its own: on the drains' copy stream these copies would queue up behind / in front of
-                    # the device chunks' length and byte transfers)
-                    with torch.cuda.stream(hcopy):
-                        hcopy.wait_event(ready)
-                        stage[t0:t0 + m].copy_(hsym, non_blocking=True)
-                        if use16:
-                            st_f[k:k + 1].copy_(hflag[k:k + 1], non_blocking=True)
-                        landed = torch.cuda.Event()
-                        landed.record(hcopy)
-                    entry = (k, t0, m, hsym, landed)
-                if pending is not None:
-                    host_encode(pending)
-                pending = entry
-            if pending is not None:
-                host_encode(pending)
+            # a software pipeline in this thread: with sub-chunks 0 .. p - 1 queued, queue sub-chunk k + p, then code k
+            ahead = max(1, len(prequeued))
+            entries = list(prequeued)
+            for k in range(len(subs)):
+                while len(entries) < min(len(subs), k + ahead + 1):
+                    entries.append(queue_sub(len(entries)))
+                host_encode(entries[k])
+                entries[k] = None
         except _HostRange:  # a symbol outside 16 bits: the whole call again with 32-bit symbols for the host's tiles
             torch.cuda.synchronize(dev)
             del queued

@@ -501,6 +501,8 @@ def decompress_chunked(net, strings, shape, chunk=1024):
         keep.append((data, byte_off))
         events.append(ev)
     sec.mark("d.queue H2D+decode")
+    if host_trace is not None:
+        host_trace.append(("dec-launches-queued", len(pieces), time.perf_counter()))
     fp16 = net.precision == "fp16"
 
     def synthesise(s0, n, symbols, stride_b, stride_i, sym_offset=0):
@@ -578,7 +580,7 @@ def decompress_chunked(net, strings, shape, chunk=1024):
                     synthesise16(t0, m, hsym)
             keep.append((hsym,))
             if host_trace is not None:
-                host_trace.append(("dec", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3)))
+                host_trace.append(("dec", m, round(1e3 * (w1 - w0), 3), round(1e3 * (w2 - w1), 3), round(1e3 * (time.perf_counter() - w2), 3), w0))
             if not queued_device:
                 packed_ev = torch.cuda.Event()
                 packed_ev.record(hsyn)
@@ -589,6 +591,8 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             main.wait_stream(hsyn)
     else:
         synthesise_device_pieces()
+    if host_trace is not None:
+        host_trace.append(("dec-all-queued", n_host, time.perf_counter()))
     sec.mark("d.decode+transforms (device)")
     if int(status.item()) != 0:  # synchronises; also keeps data/sym alive until the side stream is done
         raise ValueError("licos_amd: a rANS string ended before all symbols were decoded")

@@ -17,9 +17,10 @@ with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        tr, codec.host_trace = codec.host_trace, None
+        tr, codec.host_trace = codec.host_trace, ([] if it == 4 else None)
         d = net.decompress(c["strings"], c["shape"])
         torch.cuda.synchronize(); t2 = time.perf_counter()
+        trd, codec.host_trace = codec.host_trace, None
         print("iter %d: compress %.2f ms decompress %.2f ms" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1)), flush=True)
 for e in tr:
     if e[0] == "enc":
@@ -27,3 +28,10 @@ for e in tr:
     else:
         print("  %-16s %5d at %7.2f ms" % (e[0], e[1], 1e3 * (e[2] - t0)))
 print("  (end of compress at %.2f ms)" % (1e3 * (t1 - t0)))
+print("decompress (from %.2f ms):" % 0.0)
+for e in trd:
+    if e[0] == "dec":
+        print("  host sub-chunk %4d tiles at %7.2f ms: joined %.2f, decoded %.2f, queued its upload + transforms in %.2f" % (e[1], 1e3 * (e[5] - t1), e[2], e[3], e[4]))
+    else:
+        print("  %-20s %5d at %7.2f ms" % (e[0], e[1], 1e3 * (e[2] - t1)))
+print("  (end of decompress at %.2f ms)" % (1e3 * (t2 - t1)))

@@ -38,8 +38,8 @@ NATIVE_WATCHDOG_S = float(os.environ.get("LICOS_NATIVE_WATCHDOG_S", "120"))  # t
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=5)  # (the host's share of a call settles on the box's host rate in the first calls)
     ap.add_argument("--batch", type=int, default=16384, help="tiles per GPU per step")
     ap.add_argument("--chunk", type=int, default=4096, help="tiles per pipeline chunk inside a step")
     ap.add_argument("--channels", type=int, default=3)
@@ -567,9 +567,13 @@ def main():
         comp, dec = step()
     fence()
     engine.stage_events = {} if args.precision == "fp16" else None
+    if "LICOS_STAGE_EVENTS_MIN" not in os.environ:
+        engine.stage_events_min_batch = 512  # the chunk-sized launches: `roofline` and `stages` are about them
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         comp, dec = step()
+        step_ends.append(time.perf_counter())  # (decompress ends with a status read: the step is complete here)
     fence()
     elapsed = time.perf_counter() - t0
     events, engine.stage_events = engine.stage_events, None
@@ -722,6 +726,7 @@ def main():
                                                                                   args.channels, args.size, args.size, B),
                            "tiles_per_gpu_per_step": B, "precision": args.precision, "weights": weights},
                 "bpp_actual": round(bpp, 4), "psnr_db": round(psnr, 3),
+                "steps_ms": [round(1e3 * (b_ - a_), 2) for a_, b_ in zip([t0] + step_ends[:-1], step_ends)],
                 "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
                 "stages": stages,
             }

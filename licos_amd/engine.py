@@ -26,8 +26,13 @@ _cache = weakref.WeakKeyDictionary()
 stage_events = None
 
 
+# (stages launched on fewer tiles than this are not timed: the sub-chunks of the host's share are a hundred small launches
+# per step, and two events around each are ~2 ms of a 196-ms step; bench.py sets it for its timed region)
+stage_events_min_batch = int(os.environ.get("LICOS_STAGE_EVENTS_MIN", "0"))
+
+
 def _timed(key, fn):
-    if stage_events is None:
+    if stage_events is None or key[5] < stage_events_min_batch:
         return fn()
     sink = ops.stage_event_sink = []  # filled by ops._launch around the stage's C call (not around its output allocation)
     try:

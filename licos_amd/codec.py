@@ -164,6 +164,12 @@ def _note_host_rate(direction, tiles, nsym, seconds, expect_ns=None):
 
 
 _cap_state = {}
+# compress calls of up to this many capacities stay host-only: the host pipeline (transforms, 16-bit symbols over PCIe, coder)
+# moves a tile in 5.5 - 7 us at 16 threads, about what the transforms alone take, while a device chunk adds its launch's
+# latency and its drain - A/B on one box, ms per call, host-only against the split: 2048 tiles 14.3 - 15.2 vs 16.5, 3000
+# tiles 19.9 - 21.1 vs 22.0, 4096 tiles equal; with 12 / 8 threads (capacity 800 / 544) the same up to 1.75 capacities
+# (profiles/r04_enc_all_host.log)
+ENC_ALL_HOST = float(os.environ.get("LICOS_ENC_ALL_HOST", "3.0"))
 ENC_TAIL = float(os.environ.get("LICOS_ENC_TAIL_FRACTION", "1.0"))  # share of the capacity at the end of a larger compress call
 
 
@@ -200,8 +206,8 @@ def host_share(batch, direction):
     if not HOST_SPLIT:
         return 0
     cap = host_capacity(direction)
-    if batch <= cap:
-        return batch
+    if batch <= cap or (direction == "enc" and batch <= ENC_ALL_HOST * cap):
+        return batch  # (a compress call a little over the capacity: the host finishing late costs less than a device chunk's drain)
     return cap if direction == "dec" else int(ENC_TAIL * cap)
 
 

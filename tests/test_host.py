@@ -418,7 +418,9 @@ def test_host_share_of_a_call(monkeypatch):
     for b in (1, 16, 64, 384):
         assert codec.host_share(b, "enc") == b and codec.host_share(b, "dec") == b  # the host-only batches of rounds 2 - 3
     assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(cap_d + 1, "dec") == cap_d  # split: the call's first tiles
-    assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(cap_e + 1, "enc") == int(codec.ENC_TAIL * cap_e)  # ... its last
+    edge = int(codec.ENC_ALL_HOST * cap_e)
+    assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(edge, "enc") == edge  # a little over: still all
+    assert codec.host_share(edge + 1, "enc") == int(codec.ENC_TAIL * cap_e)  # ... then the call's last tiles
     assert codec.host_share(16384, "enc") == int(codec.ENC_TAIL * cap_e) and codec.host_share(16384, "dec") == cap_d  # the exposed ends
     monkeypatch.setattr(codec, "HOST_SPLIT", False)
     assert codec.host_share(1000, "enc") == 0 and codec.host_share(64, "enc") == 64

@@ -294,6 +294,19 @@ def extras(args, net, x, dev):
     for b in (1, 16, 64, 1024):
         if b <= x.shape[0]:
             out["batches"]["B%d" % b] = timed_codec(net, x[:b].contiguous(), 5 if b >= 1024 else 9, split=True)[0]
+    # the same cells with the DEVICE coder only (LICOS_HOST_CODER=0: no tile of any call is coded by the host cores): what
+    # the MI355X does by itself; the cells above are what the MI355X and 16 threads of its host do together
+    from licos_amd import ops
+    keep_hc, ops.HOST_CODER = ops.HOST_CODER, "0"
+    try:
+        out["batches_device_only"] = {}
+        for b in (1, 16, 64, 1024):
+            if b <= x.shape[0]:
+                out["batches_device_only"]["B%d" % b] = timed_codec(net, x[:b].contiguous(), 3 if b >= 1024 else 5, split=True)[0]
+        hb_ = min(x.shape[0], args.batch)
+        out["batches_device_only"]["B%d" % hb_] = timed_codec(net, x[:hb_], 3, split=True)[0]
+    finally:
+        ops.HOST_CODER = keep_hc
     # twice the headline's step: the un-hidden coder latency (one decode head + one encode tail per compress /
     # decompress call, ~19 ms whatever the batch) amortised over twice the tiles
     torch.cuda.empty_cache()  # (the step's 13 GB blocks cannot back 26 GB tensors: without this every run re-allocates)
@@ -402,7 +415,7 @@ def hyperprior_grid(args, dev):
     x = synthetic.tiles(max(sizes), 13, 512, seed=300, kind="s2-merged", device=dev)
 
     def arm():
-        engine.stage_events, codec.coder_events = {}, {}
+        engine.stage_events, codec.trace.coder_events = {}, {}
 
     for b in sizes:
         xb = x[:b]
@@ -413,8 +426,8 @@ def hyperprior_grid(args, dev):
         res["timed_calls"], res["untimed_calls"] = 5, 3 if b >= 2048 else 1
         res["gflops_frac_of_peak"] = round(54.76e9 * res["tiles_s"] / 1e12 / PEAK_F16_TFLOPS, 4)
         if engine.stage_events is not None:
-            ev, cev = engine.stage_events, codec.coder_events
-            engine.stage_events = codec.coder_events = None
+            ev, cev = engine.stage_events, codec.trace.coder_events
+            engine.stage_events = codec.trace.coder_events = None
             nbytes = sum(len(s) for lst in c["strings"] for s in lst)
             res["bpp_actual"] = round(nbytes * 8.0 / (b * 512 * 512), 4)
             res["psnr_db"] = round(licos_amd.metrics.compute_psnr(d["x_hat"], xb), 3)
@@ -447,6 +460,17 @@ def hyperprior_grid(args, dev):
             res["coders"] = coders
         out["B%d" % b] = res
         del c, d
+    # the same calls with the device coders only (no host share): the MI355X by itself
+    from licos_amd import ops
+    keep_hc, ops.HOST_CODER = ops.HOST_CODER, "0"
+    try:
+        out["device_only"] = {}
+        for b in [b_ for b_ in (4096, 256) if b_ in sizes]:
+            r_, c, d = timed_codec(net, x[:b], 3, split=True, warmup=2 if b >= 2048 else 1)
+            out["device_only"]["B%d" % b] = r_
+            del c, d
+    finally:
+        ops.HOST_CODER = keep_hc
     # "matched": the trained point against the CPU oracle on the same two tiles
     if not args.no_cpu_baseline:
         from oracle import model as om
@@ -703,6 +727,8 @@ def main():
                              "cell (%d threads)"
                              % (dt, os.cpu_count() or 0, threads)}
 
+    from licos_amd import codec as _codec
+    host_rec = _codec.placement.describe()  # (after every timed region: the factor is what this box's host delivered)
     import threading
     emit_lock = threading.Lock()
     emitted = [False]
@@ -730,9 +756,24 @@ def main():
                 "roofline": roof, "roofline_g_a2": roof_a3, "cpu_baseline": cpu, "fedavg_allreduce": fed, "grid": grid,
                 "stages": stages,
             }
-            # the driver keeps the TAIL of the line: the small per-batch table rides at the very end
-            if grid and "batches" in grid:
-                line["batches"] = grid["batches"]
+            # the driver keeps the TAIL of the line: the small tables ride at the very end.  `host` says what the host cores
+            # contributed (threads, the tiles of a large call they code, the measured slow-down factor of this box's host);
+            # `*_device_only` are the same cells with LICOS_HOST_CODER=0 - the MI355X by itself.
+            line["host"] = host_rec
+            if grid:
+                tail = {}
+                if "fp32_path_B%d" % min(B, 16384) in grid:
+                    tail["fp32_path_B%d" % min(B, 16384)] = grid["fp32_path_B%d" % min(B, 16384)]
+                h5 = grid.get("configs", {}).get("hyperprior_13x512", {})
+                tail["config5"] = {k: {kk: h5[k][kk] for kk in ("ms", "tiles_s", "encode_ms", "decode_ms") if kk in h5[k]}
+                                   for k in ("B4096", "B2048", "B256") if k in h5}
+                if "device_only" in h5:
+                    tail["config5_device_only"] = h5["device_only"]
+                line["tail"] = tail
+                if "batches_device_only" in grid:
+                    line["batches_device_only"] = grid["batches_device_only"]
+                if "batches" in grid:
+                    line["batches"] = grid["batches"]
             print(json.dumps(line), file=json_out)
             json_out.flush()
 

@@ -498,7 +498,10 @@ __global__ __launch_bounds__(256) void gc_host_words_kernel(const float *__restr
                                                            const float *__restrict__ table, int levels, float scale_bound,
                                                            int32_t *__restrict__ packed, uint8_t *__restrict__ rows8,
                                                            int32_t *__restrict__ flag, long total) {
-  const bool vec = (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(scales) | (PACK ? reinterpret_cast<uintptr_t>(y) : 0)) & 15) == 0;
+  // (the outputs' alignment counts too: these are public C-ABI entry points, a caller may pass an offset view of a staging
+  // buffer - that takes the element-wise path instead of a misaligned vector store)
+  const bool vec = (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(scales) | (PACK ? reinterpret_cast<uintptr_t>(y) : 0)) & 15) == 0 &&
+                   (PACK ? (reinterpret_cast<uintptr_t>(packed) & 15) == 0 : (reinterpret_cast<uintptr_t>(rows8) & 3) == 0);
   bool over = false;
   for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long)gridDim.x * blockDim.x * 4) {
     float sv[4], yv[4] = {0.f, 0.f, 0.f, 0.f};

@@ -110,6 +110,24 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
                : "v"(gsrc), "s"(m0v));
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane: no address VGPR pair per request
+// (a kernel that requests a dozen different pieces per step otherwise keeps a dozen hoisted 64-bit addresses alive).
+__device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, void *lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+  const uint64_t bits = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits);
+  unsigned keep;
+  uint64_t base_copy;
+  // (the base goes through an s_mov inside the statement: a base the compiler has just produced with v_readfirstlane /
+  // v_readlane needs five wait states before a vector-memory instruction may read it as its scalar address, and the
+  // compiler pads nothing inside an asm statement; an SALU read of it is interlocked)
+  asm volatile("s_mov_b64 %1, %4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(base_copy)
+               : "v"(voff), "s"(m0v), "s"(sb));
+}
+
 // Transposed conv (mfma_deconv.hip): a workgroup owns ONE output phase (py, px) of a TH x TW input tile.  The
 // (TH+2) x (TW+2) input patch of a cin chunk is staged once, as granules [half][row][x], double-buffered by chunk;
 // a K-step is (cin chunk, kernel row of the phase): it reads the patch at row offset dy = 1 - iky and needs that

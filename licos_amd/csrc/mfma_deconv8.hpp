@@ -76,9 +76,14 @@ __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8
 // ---- epilogue of one accumulator set: (I)GDN per pixel tile (squares converted once), fp16 pack, 16-byte stores ----
 // pix[nt]: index of the lane's output pixel inside the image's [Ho * Wo] plane, or -1 (outside the map: nothing stored).
 // y_img: the image's first output element; a 16-channel chunk of the image is plane_px * 16 halfs.
-template <int MT, int NT, int EPI>
+// `hook(block)` runs after each of the NT * MT (pixel tile, 32-channel tile) blocks, block = nt * MT + it: kernels whose
+// waves take turns between K loop and epilogue (mfma_first16.hip, duo form) join the workgroup's barriers there.
+struct EpilogueNoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int MT, int NT, int EPI, class Hook = EpilogueNoHook>
 __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16x8 *s_gamma, const float *s_beta, _Float16 *y_img,
-                                               size_t plane_px, int Cout16, const long (&pix)[NT], int lane) {
+                                               size_t plane_px, int Cout16, const long (&pix)[NT], int lane, Hook hook = Hook()) {
   constexpr bool NORM = (EPI == EPI_GDN || EPI == EPI_IGDN) && LICOS_ABL != 2;
   const int h = lane >> 5;
   const unsigned chunk_bytes = (unsigned)plane_px * 32u;  // one 16-channel chunk of the image
@@ -165,8 +170,16 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
             // vector-issue bound; the launchers check that an image's output stays below 4 GB).
             // (the s_nop covers the ISA's manual wait state between a store of more than 64 bits and the next write of
             // its data registers, which the compiler cannot see through the asm)
+            // (the base goes through an s_mov inside the statement: when the register allocator has spilled it to a VGPR
+            // lane it comes back through v_readlane, and a vector-memory instruction that reads an SGPR within five wait
+            // states of a VALU write of it reads garbage - a hazard the compiler pads for only where it can see the
+            // instruction; an SALU read is interlocked)
             const unsigned off = pix_off[nt] + (unsigned)chunk * chunk_bytes;
-            asm volatile("global_store_dwordx4 %0, %1, %2 " LICOS_STORE_BITS "\n\ts_nop 1" ::"v"(off), "v"(val), "s"(y_base) : "memory");
+            uint64_t base_copy;
+            asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0 " LICOS_STORE_BITS "\n\ts_nop 1"
+                         : "=&s"(base_copy)
+                         : "v"(off), "v"(val), "s"(y_base)
+                         : "memory");
           } else {
             _Float16 *dst = y_img + ((size_t)chunk * plane_px + (size_t)pix[nt]) * 16 + 8 * h;
             *reinterpret_cast<uint4 *>(dst) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
@@ -176,6 +189,7 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
       // one 32-channel tile at a time: letting the scheduler interleave the four norm chains costs 48 more live
       // registers than the kernel has, and a spill reload is a vmcnt event (see the counted waits of the callers)
       __builtin_amdgcn_sched_barrier(0);
+      hook(nt * MT + it);
     }
   }
 }

@@ -185,6 +185,23 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_kernel(FirstArgs a, in
 // buffer and one patch buffer (78 KB per workgroup: still two per CU):
 //   K loop (patch) | wait: raw rows of tile t+1 landed | barrier | repack raw -> patch | barrier | request raw rows of
 //   tile t+2 | epilogue of tile t, stores
+// LICOS_STAMPS (diagnostic builds, never the product): per-phase s_memtime cycles of wave 0, see mfma_first16.hip
+#ifdef LICOS_STAMPS
+__device__ unsigned long long g_first_stamps[32];
+#define F_STAMP(i)                                                     \
+  do {                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    st_acc[i] += now_ - st_prev;                                       \
+    st_prev = now_;                                                    \
+  } while (0)
+#else
+#define F_STAMP(i) do {} while (0)
+#endif
+// LICOS_ABL_FIRST (diagnostic builds): 5 = no LDS-to-LDS repack (timing only: the patch keeps the first tile's values)
+#ifndef LICOS_ABL_FIRST
+#define LICOS_ABL_FIRST 0
+#endif
+
 struct FirstRawArgs {
   const float *x;      // NCHW fp32 [B][C][H][W]
   const half8 *wp;     // [5 ky][MT][64] A fragments + one granule of zeros
@@ -333,7 +350,11 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_raw_kernel(FirstRawArg
   const int Cout16 = (a.Cout + 15) >> 4;
   _Float16 *y_img = a.y_blk + (size_t)b * Cout16 * a.Ho * a.Wo * 16;
   bool counted = false;  // the youngest NSTORE operations of this wave are the previous tile's stores
+#ifdef LICOS_STAMPS
+  unsigned long long st_acc[8] = {}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < t_count; ++t) {
+    F_STAMP(7);
     const unsigned char *pb = reinterpret_cast<const unsigned char *>(s_p) + lane_boff;
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
@@ -354,12 +375,17 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_raw_kernel(FirstRawArg
     }
     // the raw rows of tile t+1 (requested before the previous epilogue, or above) have landed: everything older than this
     // wave's last NSTORE operations is complete; after the barrier nobody reads the patch of tile t any more
+    F_STAMP(0);
     if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    F_STAMP(1);
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < t_count) repack();
+    F_STAMP(2);
+    if (t + 1 < t_count && LICOS_ABL_FIRST != 5) repack();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    F_STAMP(3);
     __builtin_amdgcn_s_barrier();
+    F_STAMP(4);
     if (t + 2 < t_count) dma_raw(t + 2);  // the raw buffer is free now
     asm volatile("" ::: "memory");        // the stores below stay behind that request
     const int tile = t_first + t;
@@ -372,10 +398,19 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_raw_kernel(FirstRawArg
       pix[nt] = (oy < a.Ho && ox < a.Wo) ? (long)oy * a.Wo + ox : -1;
       all_live = all_live && oy < a.Ho;
     }
+    F_STAMP(5);
     tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, y_img, (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+    F_STAMP(6);
     counted = all_live;
     if (t + 1 < t_count) acc_init();
   }
+#ifdef LICOS_STAMPS
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_first_stamps[i], st_acc[i]);
+    atomicAdd(&g_first_stamps[8], (unsigned long long)t_count);
+  }
+#endif
 }
 
 // NCHW fp32 -> [B][H + 4][rsg] fp16, value (c, iy, ix) at half (iy + 2) * rsg + (ix + 2) * C + c, zeros elsewhere.  A
@@ -495,6 +530,17 @@ static int launch_first_raw_epi(const FirstRawArgs &a, int epi, hipStream_t s) {
 using namespace licos;
 
 extern "C" {
+
+#ifdef LICOS_STAMPS
+int licos_debug_first_stamps(unsigned long long *out, int reset) {
+  if (out) LICOS_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_first_stamps), sizeof(unsigned long long) * 32));
+  if (reset) {
+    unsigned long long z[32] = {};
+    LICOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_first_stamps), z, sizeof(z)));
+  }
+  return LICOS_OK;
+}
+#endif
 
 size_t licos_hwc_pad_f16_bytes(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || C > 3 || H <= 0 || W <= 0) return 0;

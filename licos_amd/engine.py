@@ -51,8 +51,8 @@ def _pver(p):
 SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the scatter-form last stage
 FIRST_ROWS = os.environ.get("LICOS_FIRST", "1") != "0"  # kernel-row first stage (1..3 bands) instead of the space-to-depth 3x3 form
 FIRST_RAW = os.environ.get("LICOS_FIRST_RAW", "1") != "0"  # ... reading the NCHW fp32 image in place (no layout pass) when W % 4 == 0
-ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"
-FIRST16 = os.environ.get("LICOS_FIRST16", "1") != "0"  # 5..16 bands: the first stage on the NCHW fp32 image in place (csrc/mfma_first16.hip)  # row-walking last stage (1..3 bands) instead of the scatter form
+ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
+FIRST16 = os.environ.get("LICOS_FIRST16", "1") != "0"  # 5..16 bands: the first stage on the NCHW fp32 image in place (csrc/mfma_first16.hip)
 
 
 def _packed_conv(m, s2d=False, fewch=False, first=False):
@@ -142,12 +142,17 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
                       and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in and x.shape[1] <= 3
                       and st[0][0].out_channels <= 128 and len(st) > 1 and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse)
                       and min(h0, w0) >= 16)
-        first_raw = first_rows and FIRST_RAW and w0 % 4 == 0
+        # (the in-place forms read 16-byte granules of the fp32 rows: a view whose storage offset breaks that alignment takes
+        # the layout-pass routes, which accept any pointer)
+        x = x.contiguous()
+        aligned16 = x.data_ptr() % 16 == 0
+        first_raw = first_rows and FIRST_RAW and w0 % 4 == 0 and aligned16
         # 5..16 bands (the 13 merged Sentinel-2 bands) into 33..128 channels: in place as well, no blk16 layout pass
         first16 = (FIRST16 and isinstance(st[0][0], nn.Conv2d) and not isinstance(st[0][0], nn.ConvTranspose2d)
                    and conv_geometry(st[0][0])[:3] == (5, 2, 2) and not abs_in and 4 < x.shape[1] <= 16
                    and 32 < st[0][0].out_channels <= 128 and len(st) > 1
-                   and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse) and w0 % 4 == 0 and min(h0, w0) >= 16)
+                   and (st[0][1] is None or st[0][1] == "relu" or not st[0][1].inverse) and w0 % 4 == 0 and min(h0, w0) >= 16
+                   and aligned16)
         if first_rows or first16:
             s2d_first = False
             cur = x.contiguous() if (first_raw or first16) else ops.nchw_f32_to_hwc_pad_f16(x.contiguous())

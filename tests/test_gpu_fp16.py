@@ -537,8 +537,8 @@ def test_strings_and_tiles_do_not_depend_on_the_coder_placement(monkeypatch, pre
     net.chunk = 16
     x = om.synthetic_tiles(40, 3, 64, seed=33).to(DEV)
     share = {"enc": 0, "dec": 0}
-    monkeypatch.setattr(codec, "host_share", lambda batch, direction: min(batch, share[direction]))
-    monkeypatch.setattr(codec, "HOST_SUB", 1)  # sub-chunks of a few tiles: several of them per call
+    monkeypatch.setattr(codec.placement, "host_share", lambda batch, direction: min(batch, share[direction]))
+    monkeypatch.setattr(codec.config, "host_sub", 1)  # sub-chunks of a few tiles: several of them per call
     monkeypatch.setattr(ops, "host_threads", lambda: 4)
     with torch.no_grad():
         c0 = net.compress(x)
@@ -859,13 +859,13 @@ def test_dequantise_to_blk16_layouts_agree(b, c, h, w):
 
 @pytest.mark.parametrize("precision", ["fp16", "fp32"])
 def test_host_tiles_as_16_bit_symbols(monkeypatch, precision):
-    """The host's tiles cross PCIe as 16-bit symbols (codec.SYM16: licos_eb_symbols16 / licos_eb_dequantize16 and the
+    """The host's tiles cross PCIe as 16-bit symbols (codec.config.sym16: licos_eb_symbols16 / licos_eb_dequantize16 and the
     host coder's 16-bit entries): the strings and tiles of the 32-bit form; latents beyond 16 bits make compress fall back
     to it for the call and decompress for the sub-chunk concerned."""
     from licos_amd import codec
     monkeypatch.setattr(ops, "HOST_CODER", "1")
     monkeypatch.setattr(ops, "host_threads", lambda: 2)
-    monkeypatch.setattr(codec, "HOST_SUB", 2)  # sub-chunks of 4 tiles
+    monkeypatch.setattr(codec.config, "host_sub", 2)  # sub-chunks of 4 tiles
     sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=6, y_gain=20.0)
     net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
     net.load_state_dict(sd)
@@ -877,11 +877,11 @@ def test_host_tiles_as_16_bit_symbols(monkeypatch, precision):
         real = getattr(ops, name)
         monkeypatch.setattr(ops, name, lambda *a, _r=real, _k=key, **k: (calls.__setitem__(_k, calls[_k] + 1), _r(*a, **k))[1])
     with torch.no_grad():
-        monkeypatch.setattr(codec, "SYM16", False)
+        monkeypatch.setattr(codec.config, "sym16", False)
         c0 = net.compress(x)
         ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
         assert calls["enc16"] == 0 and calls["dec16"] == 0 and calls["dec32"] > 0
-        monkeypatch.setattr(codec, "SYM16", True)
+        monkeypatch.setattr(codec.config, "sym16", True)
         calls["dec32"] = 0
         c = net.compress(x)
         got = net.decompress(c["strings"], c["shape"])["x_hat"]
@@ -894,10 +894,10 @@ def test_host_tiles_as_16_bit_symbols(monkeypatch, precision):
         net.g_a[6].weight.mul_(1.0e5 / ymax)
         net.g_a[6].bias.mul_(1.0e5 / ymax)
         assert float(net.g_a(x).abs().max()) > 5.0e4
-        monkeypatch.setattr(codec, "SYM16", False)
+        monkeypatch.setattr(codec.config, "sym16", False)
         b0 = net.compress(x)
         bref = net.decompress(b0["strings"], b0["shape"])["x_hat"]
-        monkeypatch.setattr(codec, "SYM16", True)
+        monkeypatch.setattr(codec.config, "sym16", True)
         calls.update(enc16=0, dec16=0, dec32=0)
         b1 = net.compress(x)
         assert [bytes(s_) for s_ in b1["strings"][0]] == [bytes(s_) for s_ in b0["strings"][0]]

@@ -151,7 +151,7 @@ def test_hyper_codec_host_share_changes_nothing(monkeypatch):
     net.chunk = 8 * 16  # _chunk_for scales by the tile area: 8 tiles of 128^2 per pipeline chunk
     x = licos_amd.synthetic.tiles(21, 3, 128, seed=9, device=DEV)
     share = {"enc": 0, "dec": 0}
-    monkeypatch.setattr(codec, "hyper_host_share", lambda batch, direction="enc": share[direction])
+    monkeypatch.setattr(codec.placement, "hyper_host_share", lambda batch, direction="enc": share[direction])
     with torch.no_grad():
         c0 = net.compress(x)
         ref = net.decompress(c0["strings"], c0["shape"])["x_hat"]
@@ -211,7 +211,7 @@ def test_hyper_codec_mid_size_calls_run_the_host_pipeline(monkeypatch, request):
         c = net.compress(x)
         d = net.decompress(c["strings"], c["shape"])["x_hat"]
         assert calls == [1]
-        monkeypatch.setattr(codec, "HOST_SPLIT", False)  # the plain module path: transform, copy, one host coder call
+        monkeypatch.setattr(codec.config, "host_split", False)  # the plain module path: transform, copy, one host coder call
         assert not codec.hyper_fast_path(net, 19)
         c0 = net.compress(x)
         d0 = net.decompress(c0["strings"], c0["shape"])["x_hat"]

@@ -410,19 +410,19 @@ def test_host_share_of_a_call(monkeypatch):
     from licos_amd import codec, ops
     monkeypatch.setattr(ops, "HOST_CODER", "auto")
     monkeypatch.setattr(ops, "host_threads", lambda: 16)
-    monkeypatch.setattr(codec, "HOST_SPLIT", True)
-    monkeypatch.setattr(codec, "_cap_state", {})
-    monkeypatch.setattr(codec, "_host_factor", {"enc": 1.0, "dec": 1.0})
+    monkeypatch.setattr(codec.config, "host_split", True)
+    monkeypatch.setattr(codec.placement.rate, "cap_state", {})
+    monkeypatch.setattr(codec.placement.rate, "factor", {"enc": 1.0, "dec": 1.0})
     cap_e, cap_d = codec.host_capacity("enc"), codec.host_capacity("dec")
-    assert cap_e == int(0.85 * 16 * codec.DEV_NS["enc"] / codec.HOST_NS["enc"]) // 32 * 32 and 0 < cap_d < cap_e and cap_d % 32 == 0
+    assert cap_e == int(0.85 * 16 * codec.config.dev_ns["enc"] / codec.config.host_ns["enc"]) // 32 * 32 and 0 < cap_d < cap_e and cap_d % 32 == 0
     for b in (1, 16, 64, 384):
         assert codec.host_share(b, "enc") == b and codec.host_share(b, "dec") == b  # the host-only batches of rounds 2 - 3
     assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(cap_d + 1, "dec") == cap_d  # split: the call's first tiles
-    edge = int(codec.ENC_ALL_HOST * cap_e)
+    edge = int(codec.config.enc_all_host * cap_e)
     assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(edge, "enc") == edge  # a little over: still all
-    assert codec.host_share(edge + 1, "enc") == int(codec.ENC_TAIL * cap_e)  # ... then the call's last tiles
-    assert codec.host_share(16384, "enc") == int(codec.ENC_TAIL * cap_e) and codec.host_share(16384, "dec") == cap_d  # the exposed ends
-    monkeypatch.setattr(codec, "HOST_SPLIT", False)
+    assert codec.host_share(edge + 1, "enc") == int(codec.config.enc_tail * cap_e)  # ... then the call's last tiles
+    assert codec.host_share(16384, "enc") == int(codec.config.enc_tail * cap_e) and codec.host_share(16384, "dec") == cap_d  # the exposed ends
+    monkeypatch.setattr(codec.config, "host_split", False)
     assert codec.host_share(1000, "enc") == 0 and codec.host_share(64, "enc") == 64
     monkeypatch.setattr(ops, "HOST_CODER", "0")
     assert codec.host_share(1, "enc") == 0 and codec.host_share(16384, "dec") == 0
@@ -430,30 +430,61 @@ def test_host_share_of_a_call(monkeypatch):
     assert codec.host_share(5000, "enc") == 5000
     monkeypatch.setattr(ops, "host_threads", lambda: 1)
     monkeypatch.setattr(ops, "HOST_CODER", "auto")
-    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    monkeypatch.setattr(codec.config, "host_split", True)
     assert codec.host_share(3 * codec.host_capacity("dec") + 1, "dec") == codec.host_capacity("dec") < 64
 
 
 def test_host_capacity_follows_the_measured_host_rate(monkeypatch):
-    """codec._note_host_rate: a host that codes slower than nominal (a shared host under other tenants' load) shrinks the
+    """codec.note_host_rate: a host that codes slower than nominal (a shared host under other tenants' load) shrinks the
     share the next calls give it; a quiet one restores it; small sub-chunks and a faster-than-nominal host change nothing."""
     from licos_amd import codec, ops
     monkeypatch.setattr(ops, "host_threads", lambda: 16)
-    monkeypatch.setattr(codec, "_host_factor", {"enc": 1.0, "dec": 1.0})
-    monkeypatch.setattr(codec, "_cap_state", {})
+    monkeypatch.setattr(codec.placement.rate, "factor", {"enc": 1.0, "dec": 1.0})
+    monkeypatch.setattr(codec.placement.rate, "cap_state", {})
     cap0 = codec.host_capacity("enc")
     nsym = 49152
-    codec._note_host_rate("enc", 8, nsym, 1.0)               # too few tiles to say anything
+    codec.note_host_rate("enc", 8, nsym, 1.0)               # too few tiles to say anything
     assert codec.host_capacity("enc") == cap0
-    codec._note_host_rate("enc", 256, nsym, 256 * nsym * 0.5e-9 / 16)   # faster than nominal: the factor stays 1
+    codec.note_host_rate("enc", 256, nsym, 256 * nsym * 0.5e-9 / 16)   # faster than nominal: the factor stays 1
     assert codec.host_capacity("enc") == cap0
     for _ in range(6):
-        codec._note_host_rate("enc", 256, nsym, 256 * nsym * 9.0e-9 / 16)  # 5 x slower than the expected 1.8 ns
+        codec.note_host_rate("enc", 256, nsym, 256 * nsym * 9.0e-9 / 16)  # 5 x slower than the expected 1.8 ns
     assert cap0 / 6.0 < codec.host_capacity("enc") < cap0 / 4.0  # (on the grid of 2 tiles per thread)
-    assert codec.host_capacity("dec") == int(0.85 * 16 * codec.DEV_NS["dec"] / codec.HOST_NS["dec"]) // 32 * 32  # per direction
+    assert codec.host_capacity("dec") == int(0.85 * 16 * codec.config.dev_ns["dec"] / codec.config.host_ns["dec"]) // 32 * 32  # per direction
     for _ in range(10):
-        codec._note_host_rate("enc", 256, nsym, 256 * nsym * 1.8e-9 / 16)
+        codec.note_host_rate("enc", 256, nsym, 256 * nsym * 1.8e-9 / 16)
     assert codec.host_capacity("enc") >= 0.99 * cap0
+
+
+def test_host_rate_recovers_through_the_small_subchunks_a_small_share_hands_out(monkeypatch):
+    """after a busy-host phase the decode share of a large call drops to a few tiles per thread, `ramp` then
+    hands out only small sub-chunks - and those must be able to bring the factor back (a small sample that reads FAST is
+    evidence; one that reads slow is not, its per-call overheads dominate).  Driven through host_share and host_subchunks."""
+    from licos_amd import codec, ops
+    pl = codec.placement
+    monkeypatch.setattr(ops, "HOST_CODER", "auto")
+    monkeypatch.setattr(ops, "host_threads", lambda: 16)
+    monkeypatch.setattr(codec.config, "host_split", True)
+    monkeypatch.setattr(pl.rate, "factor", {"enc": 1.0, "dec": 1.0})
+    monkeypatch.setattr(pl.rate, "cap_state", {})
+    nsym = 49152
+    share0 = pl.host_share(16384, "dec")
+    assert share0 >= 256
+    for _ in range(8):  # a busy phase: full sub-chunks decode 8 x slower than nominal
+        pl.note_host_rate("dec", 256, nsym, 256 * nsym * 8 * codec.config.expect_ns["dec"] * 1e-9 / 16)
+    busy = pl.host_share(16384, "dec")
+    assert 0 < busy <= share0 // 6
+    subs = pl.host_subchunks(busy)
+    assert subs and max(m for _, m in subs) < 4 * 16  # nothing the old rule (>= 4 tiles per thread) would have accepted
+    for _, m in subs:  # slow small samples change nothing ...
+        pl.note_host_rate("dec", m, nsym, m * nsym * 20 * codec.config.expect_ns["dec"] * 1e-9 / 16)
+    assert pl.host_share(16384, "dec") == busy
+    for _ in range(40):  # ... a quiet host seen through the same small sub-chunks restores the share, call by call
+        for _, m in pl.host_subchunks(pl.host_share(16384, "dec")):
+            pl.note_host_rate("dec", m, nsym, m * nsym * codec.config.expect_ns["dec"] * 1e-9 / 16)
+    assert pl.host_share(16384, "dec") >= 0.9 * share0
+    pl.note_host_rate("dec", 8, nsym, 1.0)  # fewer tiles than threads: no sample at all
+    assert pl.host_share(16384, "dec") >= 0.9 * share0
 
 
 def test_hyper_host_share_policy(monkeypatch):
@@ -463,22 +494,22 @@ def test_hyper_host_share_policy(monkeypatch):
     from licos_amd import codec, ops
     monkeypatch.setattr(ops, "HOST_CODER", "auto")
     monkeypatch.setattr(ops, "host_threads", lambda: 16)
-    monkeypatch.setattr(codec, "HOST_SPLIT", True)
-    monkeypatch.setattr(codec, "_host_factor", {"enc": 1.0, "dec": 1.0})
-    monkeypatch.setattr(codec, "_hyper_share", {})
-    monkeypatch.delenv("LICOS_HYPER_SHARE", raising=False)
+    monkeypatch.setattr(codec.config, "host_split", True)
+    monkeypatch.setattr(codec.placement.rate, "factor", {"enc": 1.0, "dec": 1.0})
+    monkeypatch.setattr(codec.placement.rate, "hyper_share", {})
+    monkeypatch.setattr(codec.config, "hyper_share", -1)
     for d in ("enc", "dec"):
-        cap = 0.85 * 16 * codec.HYPER_DEV_NS[d] / codec.HYPER_HOST_NS[d]
+        cap = 0.85 * 16 * codec.config.hyper_dev_ns[d] / codec.config.hyper_host_ns[d]
         want = int(cap) // 64 * 64
         assert want >= 128
         assert codec.hyper_host_share(4096, d) == want == codec.hyper_host_share(2048, d)
         assert codec.hyper_host_share(600, d) == 192 and codec.hyper_host_share(400, d) == 128  # a third of the call at most
-        codec._host_factor[d] = cap / (want - 40.0)   # the host a little slower: under a step, the share stays
+        codec.placement.rate.factor[d] = cap / (want - 40.0)   # the host a little slower: under a step, the share stays
         assert codec.hyper_host_share(4096, d) == want
-        codec._host_factor[d] = 2.0                    # half the rate: half the share (on the grid)
+        codec.placement.rate.factor[d] = 2.0                    # half the rate: half the share (on the grid)
         assert codec.hyper_host_share(4096, d) == int(cap / 2) // 64 * 64
-    monkeypatch.setattr(codec, "HOST_SPLIT", False)
+    monkeypatch.setattr(codec.config, "host_split", False)
     assert codec.hyper_host_share(4096) == 0
-    monkeypatch.setattr(codec, "HOST_SPLIT", True)
+    monkeypatch.setattr(codec.config, "host_split", True)
     monkeypatch.setattr(ops, "HOST_CODER", "0")
     assert codec.hyper_host_share(4096, "dec") == 0

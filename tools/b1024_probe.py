@@ -1,4 +1,4 @@
-"""Dev probe: where a 1024-tile call's encode goes (codec.host_trace) and what the queueing costs."""
+"""Dev probe: where a 1024-tile call's encode goes (codec.trace.host_trace) and what the queueing costs."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import licos_amd
@@ -10,7 +10,7 @@ net.chunk = 4096
 x = synthetic.tiles(1024, 3, 256, seed=5, kind="aid", device=dev)
 with torch.no_grad():
     for it in range(4):
-        codec.host_trace = [] if it == 3 else None
+        codec.trace.host_trace = [] if it == 3 else None
         torch.cuda.synchronize(); t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -19,25 +19,25 @@ with torch.no_grad():
         print("iter %d: encode %.2f ms decode %.2f ms" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1)))
         if it == 3:
             tq = time.perf_counter()
-            codec.timings = {}
+            codec.trace.timings = {}
             net.decompress(c["strings"], c["shape"])
-            print("decode sections (each mark synchronises):", {k: round(1e3 * v, 2) for k, v in codec.timings.items()})
-            codec.timings = None
+            print("decode sections (each mark synchronises):", {k: round(1e3 * v, 2) for k, v in codec.trace.timings.items()})
+            codec.trace.timings = None
             for share in (0, 192, 256, 320, 391, 450, 520, 600):
-                real = codec.host_share
-                codec.host_share = lambda b, d, s_=share: (min(b, s_) if d == "dec" else real(b, d))
+                real = codec.placement.host_share
+                codec.placement.host_share = lambda b, d, s_=share: (min(b, s_) if d == "dec" else real(b, d))
                 ts = []
                 for _ in range(4):
                     torch.cuda.synchronize(); ta = time.perf_counter()
                     net.decompress(c["strings"], c["shape"])
                     torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - ta))
                 print("decode with host share %d: median %.2f ms (min %.2f)" % (share, sorted(ts)[2], min(ts)))
-                codec.host_share = real
-    print(codec.host_trace)
-    codec.host_trace = None
+                codec.placement.host_share = real
+    print(codec.trace.host_trace)
+    codec.trace.host_trace = None
     # the GPU side alone: transforms + quantise of the same sub-chunks, no host work
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for (s0, m) in codec._ramp(1024, 32, 256):
+    for (s0, m) in codec.ramp(1024, 32, 256):
         y = net.g_a(x[s0:s0 + m])
     torch.cuda.synchronize()
     print("g_a over the ramp: %.2f ms; one launch of 1024: " % (1e3 * (time.perf_counter() - t0)), end="")

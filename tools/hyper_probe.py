@@ -28,11 +28,11 @@ with torch.no_grad():
     for it in range(iters):
         if it >= 2:
             if it > 2:
-                print("   coder ms:", {k: ["%.1f" % e0.elapsed_time(e1) for e0, e1 in v] for k, v in codec.coder_events.items()},
+                print("   coder ms:", {k: ["%.1f" % e0.elapsed_time(e1) for e0, e1 in v] for k, v in codec.trace.coder_events.items()},
                       "stages %.1f ms" % sum(e0.elapsed_time(e1) for v in engine.stage_events.values() for e0, e1 in v))
-            codec.coder_events, engine.stage_events = {}, {}
+            codec.trace.coder_events, engine.stage_events = {}, {}
         torch.cuda.synchronize()
-        codec.host_trace = [] if "--trace" in sys.argv else None
+        codec.trace.host_trace = [] if "--trace" in sys.argv else None
         t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize()
@@ -40,9 +40,9 @@ with torch.no_grad():
         d = net.decompress(c["strings"], c["shape"])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if codec.host_trace is not None:
-            tr, codec.host_trace = codec.host_trace, None
-            print("  enc factor %.2f" % codec._host_factor["enc"])
+        if codec.trace.host_trace is not None:
+            tr, codec.trace.host_trace = codec.trace.host_trace, None
+            print("  enc factor %.2f" % codec.placement.rate.factor["enc"])
             for e in tr:
                 print("  ", e[:2], ["%.1f" % (1e3 * (v - t0)) if e[0] not in ("hyper-enc", "hyper-dec") else v for v in e[2:]])
         ms_ = torch.cuda.memory_stats()
@@ -51,7 +51,7 @@ with torch.no_grad():
             ms_["segment.all.allocated"], ms_["segment.all.freed"]))
         print("iter %d: compress %.1f ms, decompress %.1f ms, %.0f tiles/s" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), B / (t2 - t0)), flush=True)
 nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
-for k, evs in codec.coder_events.items():
+for k, evs in codec.trace.coder_events.items():
     ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     print(k, ["%.2f" % m for m in ms], "ns/symbol %.1f" % (1e6 * sorted(ms)[len(ms) // 2] / nsym[k[0]]))
 tot = 0.0

@@ -12,13 +12,13 @@ with torch.no_grad():
     synthetic.make_trained_like(net, seed=0)
     x = synthetic.tiles(B, 3, 256, seed=1, device=dev)
     for it in range(3):
-        codec.timings = {} if it == 2 else None
+        codec.trace.timings = {} if it == 2 else None
         torch.cuda.synchronize(); t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         d = net.decompress(c["strings"], c["shape"])
         torch.cuda.synchronize(); t2 = time.perf_counter()
 print("B=%d chunk=%d: compress %.1f ms, decompress %.1f ms" % (B, chunk, 1e3 * (t1 - t0), 1e3 * (t2 - t1)))
-for k, v in codec.timings.items():
+for k, v in codec.trace.timings.items():
     print("  %-36s %8.2f ms" % (k, 1e3 * v))
 print("bytes per tile: %.0f" % (sum(len(s) for s in c["strings"][0]) / B))

@@ -19,12 +19,12 @@ for mb in (25, 150):
             fn()
         torch.cuda.synchronize()
         print("%s %d MB pinned: %.1f GB/s" % (name, mb, 5 * mb / 1024 / (time.perf_counter() - t0)))
-real_share = codec.host_share
+real_share = codec.placement.host_share
 
 
 def run(B, share_enc, share_dec, reps=4):
     x = synthetic.tiles(B, 3, 256, seed=5, kind="aid", device=dev)
-    codec.host_share = lambda batch, direction: min(batch, share_enc if direction == "enc" else share_dec)
+    codec.placement.host_share = lambda batch, direction: min(batch, share_enc if direction == "enc" else share_dec)
     enc, dec = [], []
     with torch.no_grad():
         for i in range(reps + 1):
@@ -41,23 +41,23 @@ def run(B, share_enc, share_dec, reps=4):
 
 
 for zc in (True, False):
-    codec.ZERO_COPY = zc
+    codec.config.zero_copy = zc
     print("ZERO_COPY", zc)
     for B in (16, 64, 256):
         run(B, B, B, reps=8)
     for se, sd in ((1024, 1024), (1024, 512), (1024, 384), (768, 384)):
         run(1024, se, sd, reps=5)
-codec.ZERO_COPY = True
+codec.config.zero_copy = True
 for B in (4096, 16384):
     for se, sd in ((0, 0), (512, 256), (1024, 512), (1536, 768)):
         run(B, se, sd, reps=4 if B < 16384 else 3)
 print("default shares:", real_share(1024, "enc"), real_share(1024, "dec"), real_share(16384, "enc"), real_share(16384, "dec"))
 # section timings of one B = 1024 call at the default split
-codec.host_share = real_share
+codec.placement.host_share = real_share
 x = synthetic.tiles(1024, 3, 256, seed=5, kind="aid", device=dev)
 with torch.no_grad():
     net.decompress(*[net.compress(x)[k] for k in ("strings", "shape")])
-    codec.timings = {}
+    codec.trace.timings = {}
     c = net.compress(x); net.decompress(c["strings"], c["shape"])
-    print({k: round(1e3 * v, 2) for k, v in codec.timings.items()})
-    codec.timings = None
+    print({k: round(1e3 * v, 2) for k, v in codec.trace.timings.items()})
+    codec.trace.timings = None

@@ -1,4 +1,4 @@
-"""Dev tool: wall-clock sections of one compress() + decompress() of the bench workload (codec.timings; every mark
+"""Dev tool: wall-clock sections of one compress() + decompress() of the bench workload (codec.trace.timings; every mark
 synchronises the device, so the sections do not overlap the way the un-instrumented step does)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -16,7 +16,7 @@ with torch.no_grad():
         c = net.compress(x); torch.cuda.synchronize(); t1 = time.perf_counter()
         d = net.decompress(c["strings"], c["shape"]); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("plain: compress %.1f ms, decompress %.1f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t1)))
-    codec.timings = {}
+    codec.trace.timings = {}
     c = net.compress(x); d = net.decompress(c["strings"], c["shape"]); torch.cuda.synchronize()
-    for k, v in codec.timings.items():
+    for k, v in codec.trace.timings.items():
         print("  %-40s %7.1f ms" % (k, 1e3 * v))

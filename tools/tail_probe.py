@@ -1,4 +1,4 @@
-"""Dev probe: the timeline of the end of a large factorized compress call (codec.host_trace): when the device chunks are
+"""Dev probe: the timeline of the end of a large factorized compress call (codec.trace.host_trace): when the device chunks are
 drained, what each host sub-chunk waits for and takes, when the host is done and when the last device chunk is.
   python tools/tail_probe.py [tiles = 16384]"""
 import os, sys, time, torch
@@ -13,14 +13,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 x = synthetic.tiles(B, 3, 256, seed=5, kind="aid", device=dev)
 with torch.no_grad():
     for it in range(5):
-        codec.host_trace = [] if it == 4 else None
+        codec.trace.host_trace = [] if it == 4 else None
         torch.cuda.synchronize(); t0 = time.perf_counter()
         c = net.compress(x)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        tr, codec.host_trace = codec.host_trace, ([] if it == 4 else None)
+        tr, codec.trace.host_trace = codec.trace.host_trace, ([] if it == 4 else None)
         d = net.decompress(c["strings"], c["shape"])
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        trd, codec.host_trace = codec.host_trace, None
+        trd, codec.trace.host_trace = codec.trace.host_trace, None
         print("iter %d: compress %.2f ms decompress %.2f ms" % (it, 1e3 * (t1 - t0), 1e3 * (t2 - t1)), flush=True)
 for e in tr:
     if e[0] == "enc":

@@ -543,6 +543,14 @@ int licos_deconv5x5s2_f16_layouts(int Cin, int H, int W, int Cout);
 int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
                         int epilogue, void *y_blk16, float *y_nchw, int B, int Cin, int H, int W, int Cout,
                         void *stream);
+/* The LAST analysis stage with the entropy bottleneck's quantiser in its epilogue: symbols[b][c][h][w] =
+ * (int32) rint(conv(x)[b][c][h][w] + bias[c] - medians[c]), round-half-to-even - CompressAI EntropyBottleneck.compress's
+ * `symbols = round(x - medians).int()` on g_a's output, the one call /root/reference/eval_utils.py:199-204 makes
+ * (`net.compress`).  The layout is the coder's [stream][position] (NCHW order inside a stream): licos_rans_encode_batch
+ * reads it with sym_stride_b = Cout * Ho * Wo, sym_stride_i = 1.  Same accumulators as licos_conv5x5s2_f16 with an NCHW
+ * fp32 output followed by licos_eb_quantize: identical symbols, no fp32 latent in memory.  `medians`: [Cout] fp32. */
+int licos_conv5x5s2_f16_symbols(const void *x_blk16, const void *w_packed, const float *bias, const float *medians,
+                                int32_t *symbols, int B, int Cin, int H, int W, int Cout, void *stream);
 int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
                           int epilogue, void *y_blk16, float *y_nchw, int clamp01, int B, int Cin, int H, int W,
                           int Cout, void *stream);

@@ -122,6 +122,7 @@ SIGNATURES = {
     "licos_conv3x3s1_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_blk16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "licos_conv5x5s2_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "licos_conv5x5s2_f16_symbols": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "licos_deconv5x5s2_f16": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "licos_deconv5x5s2_f16_layouts": (_i, [_i, _i, _i, _i]),
 }

@@ -56,20 +56,30 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
     # throughput kernel writes 20 B per symbol - 1.8 ms per 4096-tile chunk on the main stream against 0.4 ms for the
     # symbols - and only the LAST launch of a call is exposed: measured, the step did not move.  LICOS_EB_RECORDS=1 switches.
     records = config.eb_records and eb.coder_image() is not None
+    # fp16 transforms: the quantiser rides in the last analysis stage's epilogue (licos_conv5x5s2_f16_symbols) and writes the
+    # symbols stream-major, [stream][position], which the plane encoder reads as each lane's own 32-byte runs - no fp32
+    # latent in memory and no transposing quantise kernel.  The fp32 parity path keeps the separate kernel.
+    fused = (not records and config.eb_stream_major and net.precision == "fp16" and not getattr(net.g_a, "fp32_only", False)
+             and engine.symbols_fusable(net.g_a))
     queued = []  # every tensor another stream touches stays referenced here until its chunk is drained
     for (s0, n) in chunks(n_dev, chunk):
-        y = net.g_a(x[s0:s0 + n])  # MFMA chain, main stream
+        if fused:
+            with torch.no_grad():
+                y = engine.run_chain_fp16(net.g_a, x=x[s0:s0 + n], symbols=(med, None))  # int32 (n, C, h, w)
+        else:
+            y = net.g_a(x[s0:s0 + n])  # MFMA chain, main stream
         if shape is None:
             shape = tuple(y.shape[-2:])
             nsym, plane = y[0].numel(), y[0, 0].numel()
-            if not records:
+            if not records and not fused:
                 sym = torch.empty((nsym, n_dev), device=dev, dtype=torch.int32)
             if cap_words is None:
                 cap_words = nsym // 2 + 64
         if records:
             keep = ops.eb_encode_prepare(y.contiguous(), med, table, cdf_len, offset, cdf.shape[1])
         else:
-            ops.eb_quantize(y, med, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=n_dev, sym_offset=s0)
+            if not fused:
+                ops.eb_quantize(y, med, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=n_dev, sym_offset=s0)
             keep = y
         ready = torch.cuda.Event()
         ready.record(main)
@@ -77,6 +87,8 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
             side.wait_event(ready)
             if records:
                 words, nwords, status = ops.rans_encode_records(keep[0], keep[1], cap_words)
+            elif fused:
+                words, nwords, status = ops.rans_encode_batch(y, nsym, 1, nsym, plane, cdf, cdf_len, offset, table, cap_words, n)
             else:
                 words, nwords, status = ops.rans_encode_batch(sym, 1, n_dev, nsym, plane, cdf, cdf_len, offset, table, cap_words,
                                                               n, sym_offset=s0)

@@ -172,6 +172,7 @@ struct MfmaArgs {
   int in_xsplit, out_xsplit;  // LICOS_EPI_IN_XSPLIT / LICOS_EPI_OUT_XSPLIT (mfma_deconv8.hip only)
   int w_mt_total, halves;     // mfma_conv8.hip pair mode: 32-channel tiles in the packed weights, channel groups per tile
   int out_split3;             // LICOS_EPI_OUT_SPLIT3: y_blk holds 3 Cout channels, the split operand of the next fp32 convolution
+  const float *sym_medians;   // licos_conv5x5s2_f16_symbols: y_nchw receives int32 rint(result - median[channel]) instead of the fp32 result
 };
 
 // ---- epilogue: bias, (I)GDN, store ----------------------------------------------------------------
@@ -271,6 +272,10 @@ __device__ __forceinline__ void epilogue_store_tile(const f32x16 &acc, const f32
         if (epi_norm(EPI)) v *= (*scale)[4 * g + e];
         if (live && c0 + e < a.Cout) {
           float *dst = a.y_nchw + (((size_t)b * a.Cout + c0 + e) * a.Ho + oy) * a.Wo + ox;
+          if (a.sym_medians) {  // the entropy bottleneck's symbol, [stream][position]: round-half-to-even as torch.round
+            *reinterpret_cast<int32_t *>(dst) = (int32_t)rintf(v - a.sym_medians[c0 + e]);
+            continue;
+          }
           if (a.accum) v = fmaf(v, a.out_scale, *dst);
           if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
           if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);

@@ -561,6 +561,20 @@ int licos_conv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *
   return mfma_dispatch_conv(a, MT, kernel_epi(epilogue), a.Wo, as_stream(stream));
 }
 
+int licos_conv5x5s2_f16_symbols(const void *x_blk16, const void *w_packed, const float *bias, const float *medians,
+                                int32_t *symbols, int B, int Cin, int H, int W, int Cout, void *stream) {
+  LICOS_REQUIRE(medians && symbols, "conv5x5s2_f16_symbols: NULL buffer");
+  MfmaArgs a{};
+  int MT = 0;
+  int rc = fill_args(a, x_blk16, w_packed, bias, nullptr, EPI_NONE, nullptr, reinterpret_cast<float *>(symbols), B, Cin, H, W, Cout, &MT,
+                     "conv5x5s2_f16_symbols");
+  if (rc != LICOS_OK) return rc;
+  a.Ho = (H - 1) / 2 + 1;
+  a.Wo = (W - 1) / 2 + 1;
+  a.sym_medians = medians;
+  return mfma_dispatch_conv(a, MT, EPI_NONE, a.Wo, as_stream(stream));
+}
+
 int licos_deconv5x5s2_f16(const void *x_blk16, const void *w_packed, const float *bias, const void *gdn_packed,
                           int epilogue, void *y_blk16, float *y_nchw, int clamp01, int B, int Cin, int H, int W,
                           int Cout, void *stream) {

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
   WordSink sink{words, B, b, cap_words, false};
   uint64_t x = RANS_L;
   const int32_t *sp = symbols + (size_t)b * ssb;
+  const bool vec_ok = ssi == 1 && (plane % SYM_BATCH) == 0 && (ssb & 3) == 0 && (reinterpret_cast<uintptr_t>(symbols) & 15) == 0;  // (uniform)
   for (int c = C - 1; c >= 0; --c) {
     const int len = cdf_len[c];
     const int32_t max_value = len - 2;
@@ -193,7 +194,18 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
     if (!live) continue;  // idle lanes (last block only) sit out the coding loop: no per-symbol predication for them
     // symbols are fetched one batch ahead, so their load latency hides under the coding of the current batch
     int32_t sv_next[SYM_BATCH];
+    // stream-major symbols (ssi == 1: licos_conv5x5s2_f16_symbols writes them so): a batch is the lane's own 32 contiguous
+    // bytes - two 16-byte loads instead of eight dwords at a stride; the lines a wave touches (64 x 128 B) stay in the
+    // CU's cache for the four batches that use them
     auto fetch = [&](int p1, int32_t (&dst)[SYM_BATCH]) {
+      if (vec_ok && p1 >= SYM_BATCH) {
+        static_assert(SYM_BATCH == 8, "two int4 per batch");
+        const int4 *q = reinterpret_cast<const int4 *>(sp + (size_t)c * plane + (p1 - SYM_BATCH));
+        const int4 lo = q[0], hi = q[1];
+        dst[0] = hi.w; dst[1] = hi.z; dst[2] = hi.y; dst[3] = hi.x;
+        dst[4] = lo.w; dst[5] = lo.z; dst[6] = lo.y; dst[7] = lo.x;
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k)
         dst[k] = (p1 - 1 - k >= 0) ? sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi] : 0;

@@ -121,10 +121,22 @@ def stages(seq):
     return out
 
 
-def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
-    """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32
-    (written into `out` when given)."""
+def symbols_fusable(seq):
+    """Can the chain's last stage carry the entropy bottleneck's quantiser in its epilogue (run_chain_fp16's `symbols`)?
+    A plain 5x5 stride-2 convolution with nothing behind it - every analysis transform of the zoo."""
     st = stages(seq)
+    m, g = st[-1]
+    return (len(st) > 1 and g is None and isinstance(m, nn.Conv2d) and not isinstance(m, nn.ConvTranspose2d)
+            and conv_geometry(m)[:3] == (5, 2, 2))
+
+
+def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=None):
+    """Runs the chain on NCHW fp32 `x` (or an already blocked fp16 `x_blk`); returns NCHW fp32
+    (written into `out` when given).  symbols = (medians [C], int32 out (B, C, h, w) or None): the last stage writes
+    rint(y - median) as int32 instead of y (symbols_fusable(seq) must hold) and that tensor is returned."""
+    st = stages(seq)
+    if symbols is not None and not symbols_fusable(seq):
+        raise ValueError("licos_amd: this chain's last stage cannot carry the quantiser")
     s2d_first = False
     if x_blk is None:
         if x.dtype != torch.float32:
@@ -234,6 +246,9 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None):
                                                           out_nchw=last, clamp01=clamp01 and last,
                                                           out=out if last else None))
             xsplit = out_split
+        elif last and symbols is not None:
+            key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], norm)
+            cur = _timed(key, lambda: ops.conv5x5s2_f16_symbols(cur, wp, bp, symbols[0], m.in_channels, m.out_channels, out=symbols[1]))
         else:
             key = ("conv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], norm)
             cur = _timed(key, lambda: ops.conv5x5s2_f16(cur, wp, bp, gp, epi, m.in_channels, m.out_channels,

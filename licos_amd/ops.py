@@ -1098,6 +1098,27 @@ def conv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout,
     return y
 
 
+def conv5x5s2_f16_symbols(x_blk, w_packed, bias_padded, medians, cin, cout, out=None):
+    """The last analysis stage with the entropy bottleneck's quantiser in its epilogue (licos_conv5x5s2_f16_symbols):
+    int32 symbols (B, cout, Ho, Wo) - the coder's [stream][position] layout - written into `out` when given."""
+    _dev(x_blk, w_packed, bias_padded, medians, out)
+    b, c16, h, w, _ = x_blk.shape
+    if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:
+        raise ValueError("conv5x5s2_f16_symbols: input is not the blk16 fp16 layout of `cin` channels")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((b, cout, ho, wo), device=x_blk.device, dtype=torch.int32)
+    elif out.dtype != torch.int32 or tuple(out.shape) != (b, cout, ho, wo) or not out.is_contiguous():
+        raise ValueError("conv5x5s2_f16_symbols: `out` must be a contiguous int32 (B, cout, Ho, Wo) tensor")
+    med = _f32(medians)
+    if med.numel() != cout:
+        raise ValueError("conv5x5s2_f16_symbols: one median per output channel")
+    rc = _launch(_lib.load().licos_conv5x5s2_f16_symbols, _p(x_blk), _p(w_packed), _p(bias_padded), _p(med), _p(out), b, cin, h, w, cout,
+                 _stream())
+    _lib.check(rc, "conv5x5s2_f16_symbols")
+    return out
+
+
 def deconv5x5s2_f16(x_blk, w_packed, bias_padded, gdn_packed, epilogue, cin, cout, out_nchw=False, clamp01=False,
                     out=None):
     _dev(x_blk, w_packed, bias_padded, gdn_packed, out)

@@ -905,3 +905,56 @@ def test_host_tiles_as_16_bit_symbols(monkeypatch, precision):
         bgot = net.decompress(b1["strings"], b1["shape"])["x_hat"]
         assert calls["dec16"] > 0 and 1 <= calls["dec32"] <= calls["dec16"]
         assert torch.allclose(bgot, bref, rtol=0, atol=0, equal_nan=True)  # (latents this large overflow the synthesis)
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w", [(3, 128, 192, 32, 32), (1, 128, 192, 32, 32), (4, 128, 320, 32, 32), (2, 128, 192, 40, 72),
+                                                (2, 128, 128, 64, 64)])
+def test_quantiser_in_the_last_analysis_stage(batch, cin, cout, h, w):
+    """licos_conv5x5s2_f16_symbols (CompressAI EntropyBottleneck.compress's `round(x - medians).int()` on g_a's
+    output, /root/reference/eval_utils.py:199-204): the symbols of the convolution with the quantiser in its epilogue are
+    EXACTLY those of the same convolution's fp32 output followed by licos_eb_quantize - ties included, the accumulators are
+    the same - in the coder's [stream][position] layout; two images per pixel tile, an odd batch, M = 320, a ragged map."""
+    g = torch.Generator().manual_seed(cout + h + batch)
+    x = h16(torch.randn(batch, cin, h, w, generator=g))
+    wt = h16(torch.randn(cout, cin, 5, 5, generator=g) * 0.08)
+    b = torch.randn(cout, generator=g)
+    med = (torch.randn(cout, generator=g) * 0.7).to(DEV)
+    med[::7] = 0.5  # medians on the grid's half steps put latents on rounding ties
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    wp = ops.pack_conv_w_f16(wt.to(DEV))
+    bp = ops.pad_bias(b.to(DEV), cout, DEV)
+    y = ops.conv5x5s2_f16(xb, wp, bp, None, ops.EPI_NONE, cin, cout, out_nchw=True)
+    ho, wo = y.shape[2], y.shape[3]
+    want = torch.empty((batch, cout * ho * wo), device=DEV, dtype=torch.int32)
+    ops.eb_quantize(y, med, "symbols", symbols=want, sym_stride_b=cout * ho * wo, sym_stride_i=1)
+    got = ops.conv5x5s2_f16_symbols(xb, wp, bp, med, cin, cout)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (batch, cout, ho, wo)
+    assert torch.equal(got.view(batch, -1), want)
+    assert int(got.abs().max()) > 3  # (the operands do spread the symbols)
+    # ... and the oracle's quantiser on the same latents
+    ref = torch.round(y.cpu() - med.cpu().view(1, -1, 1, 1)).to(torch.int32)
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_fused_quantiser_and_stream_major_symbols_change_no_byte(monkeypatch):
+    """The chunk pipeline with the quantiser in g_a[6]'s epilogue and the plane encoder reading [stream][position] symbols
+    (codec.config.eb_stream_major) writes the strings of the unfused pipeline (transposing quantise kernel, [position]
+    [stream] symbols), tile for tile - several chunks, a ragged last chunk, an odd chunk size."""
+    from licos_amd import codec
+    sd = om.perturb_state(om.make_factorized_state(3, quality=1, seed=42), seed=7)
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval().set_precision("fp16")
+    net.update(force=True)
+    monkeypatch.setattr(ops, "HOST_CODER", "0")
+    x = om.synthetic_tiles(23, 3, 64, seed=5).to(DEV)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(codec.config, "eb_stream_major", fused)
+        for chunk in (7, 16):
+            net.chunk = chunk
+            with torch.no_grad():
+                c = net.compress(x)
+            out[(fused, chunk)] = [bytes(s) for s in c["strings"][0]]
+    assert out[(True, 7)] == out[(False, 7)] == out[(True, 16)] == out[(False, 16)]
+    assert len(set(out[(True, 7)])) > 1 and min(len(s) for s in out[(True, 7)]) > 8

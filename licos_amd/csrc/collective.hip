@@ -5,6 +5,7 @@
 // on it and a process never holds two copies.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -35,10 +36,19 @@ Rccl &rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     void *h = nullptr;
-    for (const char *name : {"librccl.so", "librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // PyTorch's copy, if the process has one
-      if (h) break;
+    // LICOS_RCCL_TEST_LIB (tests only): a stand-in library with librccl's C API for processes that share ONE GPU
+    // (tests/fake_rccl/fake_rccl.cpp) - RCCL refuses two ranks on one device, so on a one-GPU box the direct schedule's
+    // send / recv loop below can only be exercised through it.  Unset in production: then this is librccl or nothing.
+    const char *test_lib = getenv("LICOS_RCCL_TEST_LIB");
+    if (test_lib && *test_lib) {
+      h = dlopen(test_lib, RTLD_NOW | RTLD_LOCAL);
+      if (!h) return;  // (never fall through to the real library when a test asked for the stand-in)
     }
+    if (!h)
+      for (const char *name : {"librccl.so", "librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // PyTorch's copy, if the process has one
+        if (h) break;
+      }
     if (!h)
       for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

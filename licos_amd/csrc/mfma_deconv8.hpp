@@ -188,7 +188,9 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
       }
       // one 32-channel tile at a time: letting the scheduler interleave the four norm chains costs 48 more live
       // registers than the kernel has, and a spill reload is a vmcnt event (see the counted waits of the callers)
+#ifndef LICOS_EPI_NO_FENCE  // (A/B builds: let the scheduler overlap two blocks' chains where registers allow)
       __builtin_amdgcn_sched_barrier(0);
+#endif
       hook(nt * MT + it);
     }
   }

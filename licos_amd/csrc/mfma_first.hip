@@ -201,6 +201,9 @@ __device__ unsigned long long g_first_stamps[32];
 #ifndef LICOS_ABL_FIRST
 #define LICOS_ABL_FIRST 0
 #endif
+#ifndef LICOS_FIRST_PRIO_E
+#define LICOS_FIRST_PRIO_E 0
+#endif
 
 struct FirstRawArgs {
   const float *x;      // NCHW fp32 [B][C][H][W]
@@ -399,7 +402,13 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_first_raw_kernel(FirstRawArg
       all_live = all_live && oy < a.Ho;
     }
     F_STAMP(5);
+#if LICOS_FIRST_PRIO_E
+    __builtin_amdgcn_s_setprio(LICOS_FIRST_PRIO_E);  // (A/B) the epilogue's dependent chains ahead of the other workgroup's K loop
+#endif
     tile8_epilogue<MT, NT, EPI>(acc, s_gamma, s_beta, y_img, (size_t)a.Ho * a.Wo, Cout16, pix, lane);
+#if LICOS_FIRST_PRIO_E
+    __builtin_amdgcn_s_setprio(0);
+#endif
     F_STAMP(6);
     counted = all_live;
     if (t + 1 < t_count) acc_init();

@@ -18,10 +18,18 @@
 // the output is bit-identical to licos_nchw_f32_to_blk16 + licos_conv5x5s2_f16 (tests/test_gpu_fp16.py).
 #include <cstdlib>
 
+// This stage's output is never re-read before it has left every cache: non-temporal stores (A/B on one box, duo form,
+// 1024 tiles of 13 x 512^2: 9.61 ms against 9.72 with the write-through `sc1` the other tile kernels use; plain stores 9.86).
+#ifndef LICOS_STORE_BITS
+#define LICOS_STORE_BITS "nt"
+#endif
 #include "mfma_deconv8.hpp"
 
 namespace licos {
 
+#ifndef LICOS_F16D_PRIO_E
+#define LICOS_F16D_PRIO_E 1
+#endif
 // LICOS_STAMPS (diagnostic builds via tools/ab_build.sh, never the product): wave 0 of every workgroup adds the s_memtime
 // cycles it spent in each phase of a tile into g_first16_stamps; licos_debug_first16_stamps copies them out.
 #ifdef LICOS_STAMPS
@@ -289,7 +297,7 @@ struct First16DuoGeom {
   static constexpr int W_GRAN = 5 * MT * 64, GAMMA_GRAN = MT * MT * 2 * 64;
   static constexpr int SG = 18;
   static constexpr int POS_E = NR_E * SG, POS = (NR_E + NR_O) * SG, POS_PAD = 384;  // (row, group) positions; padded to 6 waves per band half
-  static constexpr int LDS_BYTES = 16 * (2 * SET_GRAN + 2 * W_GRAN + GAMMA_GRAN) + 2 * 32 * MT * 4;
+  static constexpr int LDS_BYTES = 16 * (2 * SET_GRAN + 2 * W_GRAN + GAMMA_GRAN) + 2 * (2 * 32 * MT * 4);  // bias | beta, twice
   static_assert(POS <= POS_PAD && 2 * POS_PAD == 3 * 256, "three rounds of 256 jobs; a wave's jobs of a round share the band half");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
   const int n_tiles = 2 * rows;  // tile k: column 2 cp + (k & 1), tile row yr * run + (k >> 1); group k & 1 owns it
   const float *xb = a.x + (size_t)b * a.C * a.H * a.W;
 #ifdef LICOS_STAMPS
-  unsigned long long st_acc[12] = {}, st_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long st_acc[20] = {}, st_prev = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- staging jobs of this thread: round q -> (band half, plane row, pixel group) --------------------------------------
@@ -354,6 +362,12 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
     }
   };
   auto raw_store = [&](const Raw &rw, int q, int set) {
+    // A use of every loaded register in UNIFORM control flow: the conversions below sit in lane-dependent branches, and a
+    // wait the compiler places inside a branch leaves its scoreboard "pending" on the path around it - it then waits for
+    // vmcnt(0) at the next reuse of these registers, which is right behind the next step's weight request (and, in the
+    // period's first step, behind this wave's own epilogue stores): 1 - 8 k cycles per tile in the first version's stamps.
+    asm volatile("" ::"v"(rw.v[0].w), "v"(rw.v[1].w), "v"(rw.v[2].w), "v"(rw.v[3].w), "v"(rw.v[4].w), "v"(rw.v[5].w), "v"(rw.v[6].w),
+                 "v"(rw.v[7].w));
     if (!((j_src[q] >> 17) & 1)) return;
     const int rg = j_src[q] >> 18;
     // pixel p of the group is patch column 4 g + p - 2 = 2 xh + par: p = 0, 1 -> xh = 2 g - 1 (par 0, 1), p = 2, 3 -> xh = 2 g;
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
 
   // ---- prologue: resident operands, the first weights (group 0), tile 0 into set 0 (group 1) -------------------------------
   if (wave == 0) glds16((lane < 32 || EPI != EPI_GDN) ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias);
+  if (wave == 1) glds16((lane < 32 || EPI != EPI_GDN) ? a.bias + 4 * (lane & 31) : a.beta + 4 * (lane & 31), s_bias + 2 * 32 * MT);  // (acc_init's second copy)
   if (EPI == EPI_GDN) {
 #pragma unroll
     for (int i = 0; i < G::GAMMA_GRAN / 64 / 8; ++i) glds16(a.gamma + (wave + 8 * i) * 64 + lane, s_gamma + (wave + 8 * i) * 64);
@@ -413,6 +428,22 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
   auto acc_init = [&]() {  // accumulators start at the bias: register q of tile mt is channel 32mt + (q&3) + 8(q>>2) + 4h
     const float *sb = s_bias_lane;
     asm volatile("" : "+v"(sb));
+#ifdef LICOS_F16D_ACC_DIRECT
+    // every accumulator quad straight from LDS (the second pixel tile from a second copy of the bias, so that the compiler
+    // does not share the read and copy 128 registers): 32 ds_read_b128 and no v_mov
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *reinterpret_cast<const float4 *>(sb + nt * (2 * 32 * MT) + 32 * mt + 8 * g);
+          acc[mt][nt][4 * g + 0] = bv.x;
+          acc[mt][nt][4 * g + 1] = bv.y;
+          acc[mt][nt][4 * g + 2] = bv.z;
+          acc[mt][nt][4 * g + 3] = bv.w;
+        }
+#else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -426,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
           acc[mt][nt][4 * g + 3] = bv.w;
         }
       }
+#endif
   };
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -456,14 +488,32 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
   for (int p = grp; p < n_tiles; p += 2) {
     {
       // ---- K role: tile p from this group's planes; tile p + 1 into the other group's ---------------------------------------
+#ifdef LICOS_F16D_PRIO
+    __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO);  // (A/B) the K role's MFMAs ahead of the SIMD partner's epilogue stream
+#endif
+#if LICOS_F16D_PRIO_E
+    __builtin_amdgcn_s_setprio(0);
+#endif
     Raw rw;
 #pragma unroll
     for (int si = 0; si < 5; ++si) {
       const int ky = (si < 3) ? 2 * si : 2 * si - 5;  // 0, 2, 4, 1, 3
+#ifdef LICOS_STAMPS
+      if (si == 0) {  // (diagnostic: the five pieces of the first step's weight request one by one)
+        F16_STAMP(13);
+#pragma unroll
+        for (int i = 0; i < 5 * MT / 4; ++i) {
+          glds16_s(a.wp, w_lane_off + (unsigned)(2 * (5 * MT * 64) + 4 * i * 64) * 16u, s_wbuf + (wcur ^ 1) * G::W_GRAN + (wl + 4 * i) * 64);
+          F16_STAMP(14 + i);
+        }
+      } else
+#endif
       if (si < 4) dma_w((si + 1 < 3) ? 2 * (si + 1) : 2 * (si + 1) - 5, wcur ^ 1);
       else if (p + 1 < n_tiles) dma_w(0, wcur ^ 1);
       asm volatile("" ::: "memory");  // the round's loads stay behind the weight request (the counted wait below)
+      if (si == 0) F16_STAMP(11);
       if (si == 0 || si == 2 || si == 4) raw_load(rw, si >> 1, p + 1);
+      if (si == 0) F16_STAMP(12);
       {
         constexpr int NI = 5 * MT;
         const half8 *s_w = s_wbuf + wcur * G::W_GRAN;
@@ -517,6 +567,14 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
     }
     {
       // ---- epilogue role: five barriers on the way ------------------------------------------------------------------------------
+#ifdef LICOS_F16D_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#if LICOS_F16D_PRIO_E
+      // the epilogue's DEPENDENT chains (norm MFMAs behind their gamma reads, rsq behind the norm) ahead of the SIMD partner's
+      // independent K-loop MFMAs: 9.61 against 9.71 ms; the other way round (K role first) changed nothing
+      __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E);
+#endif
       auto join = [&](int blk) {
         if (blk == 1 || blk == 3 || blk == 5 || blk == 6) {
           F16_STAMP(8);
@@ -545,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
 #ifdef LICOS_STAMPS
   if (tk == 0) {  // wave 0 of each group: group g's counters at 32 g
 #pragma unroll
-    for (int i = 0; i < 11; ++i) atomicAdd(&g_first16_stamps[32 * grp + i], st_acc[i]);
+    for (int i = 0; i < 19; ++i) atomicAdd(&g_first16_stamps[32 * grp + i], st_acc[i]);
     atomicAdd(&g_first16_stamps[32 * grp + 24], (unsigned long long)rows);
   }
 #endif

@@ -49,13 +49,13 @@ def run_first16(B, H):
         stamps(buf, 0)
         if os.environ.get("LICOS_FIRST16_DUO", "1") != "0":
             names = ["K s%d top+mfma" % si for si in range(5)] + ["K raw_store (3 rounds)", "K waitcnt (5)", "K barrier (5)", "E compute", "E barriers (5)",
-                                                                   "E acc_init"]
+                                                                   "E acc_init", "K s0: weight request issue", "K s0: round-0 load issue", "K s0: loop head", "K s0: piece 0", "K s0: piece 1", "K s0: piece 2", "K s0: piece 3", "K s0: piece 4"]
             for g in (0, 1):
                 n = max(1, buf[32 * g + 24])
-                tot = sum(buf[32 * g + i] for i in range(11))
+                tot = sum(buf[32 * g + i] for i in range(19))
                 print("  duo stamps, group %d, %d tile rows (wave 0 of the group), cycles per tile (8 x 32): total %.0f" % (g, n, tot / n))
-                for i in range(11):
-                    print("   %-24s %8.0f" % (names[i], buf[32 * g + i] / n))
+                for i in range(19):
+                    print("   %-28s %8.0f" % (names[i], buf[32 * g + i] / n))
         else:
             n = max(1, buf[24])
             names = []
@@ -109,9 +109,14 @@ def run_first(B):
 
 
 SWEEP = [
-    ({"LICOS_FIRST16_DUO": "1", "LICOS_HIP_SO": "build/ab/liblicos_first16_stamps.so"}, ["first16", "1024"]),
-    ({"LICOS_FIRST16_DUO": "0"}, ["first16", "1024"]),
-    ({"LICOS_FIRST16_DUO": "1"}, ["first16", "1024"]),
+    ({}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_nt.so"}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE.so"}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE_nt.so"}, ["first", "4096"]),
+    ({}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_nt.so"}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE.so"}, ["first", "4096"]),
+    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE_nt.so"}, ["first", "4096"]),
 ]
 
 

@@ -30,6 +30,9 @@ namespace licos {
 #ifndef LICOS_F16D_PRIO_E
 #define LICOS_F16D_PRIO_E 1
 #endif
+#ifndef LICOS_F16D_PRIO_YOUNG  // (A/B) static extra priority for waves 4 - 7, the arbitration losers of every SIMD pair
+#define LICOS_F16D_PRIO_YOUNG 0
+#endif
 // LICOS_STAMPS (diagnostic builds via tools/ab_build.sh, never the product): wave 0 of every workgroup adds the s_memtime
 // cycles it spent in each phase of a tile into g_first16_stamps; licos_debug_first16_stamps copies them out.
 #ifdef LICOS_STAMPS
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
     __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO);  // (A/B) the K role's MFMAs ahead of the SIMD partner's epilogue stream
 #endif
 #if LICOS_F16D_PRIO_E
-    __builtin_amdgcn_s_setprio(0);
+    if (LICOS_F16D_PRIO_YOUNG && grp == 1) __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_YOUNG);
+    else __builtin_amdgcn_s_setprio(0);
 #endif
     Raw rw;
 #pragma unroll
@@ -573,7 +577,8 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
 #if LICOS_F16D_PRIO_E
       // the epilogue's DEPENDENT chains (norm MFMAs behind their gamma reads, rsq behind the norm) ahead of the SIMD partner's
       // independent K-loop MFMAs: 9.61 against 9.71 ms; the other way round (K role first) changed nothing
-      __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E);
+      if (LICOS_F16D_PRIO_YOUNG && grp == 1) __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E + LICOS_F16D_PRIO_YOUNG);
+      else __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E);
 #endif
       auto join = [&](int blk) {
         if (blk == 1 || blk == 3 || blk == 5 || blk == 6) {

@@ -183,7 +183,28 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
   WordSink sink{words, B, b, cap_words, false};
   uint64_t x = RANS_L;
   const int32_t *sp = symbols + (size_t)b * ssb;
-  const bool vec_ok = ssi == 1 && (plane % SYM_BATCH) == 0 && (ssb & 3) == 0 && (reinterpret_cast<uintptr_t>(symbols) & 15) == 0;  // (uniform)
+  // Stream-major symbols (ssi == 1: licos_conv5x5s2_f16_symbols writes them so): a lane's symbols are one contiguous run
+  // walked backwards, channel boundaries included, so the requests run ENC_AHEAD batches (two 16-byte loads each) ahead of
+  // the coding - a wave's load touches 64 different cache lines, a round trip of microseconds that one batch of coding
+  // (1.2 us) does not cover: with one batch of look-ahead the launch took 15.9 ms instead of 7.1 (round 5, first form).
+  constexpr int ENC_AHEAD = 4;
+  const bool vec_ok = ssi == 1 && (plane % (SYM_BATCH * ENC_AHEAD)) == 0 && (ssb & 3) == 0 && (reinterpret_cast<uintptr_t>(symbols) & 15) == 0;  // (uniform)
+  int4 ring[ENC_AHEAD][2];
+  long g_next = 0;  // next batch to request: batch g is positions n - 8 (g + 1) .. n - 8 g - 1 of the stream
+  const long n_total = (long)C * plane;
+  auto request = [&](int4 (&slot)[2]) {
+    const long pos = n_total - (long)SYM_BATCH * (g_next + 1);
+    if (pos >= 0) {
+      const int4 *q = reinterpret_cast<const int4 *>(sp + pos);
+      slot[0] = q[0];
+      slot[1] = q[1];
+    }
+    ++g_next;
+  };
+  if (vec_ok && live) {
+#pragma unroll
+    for (int j = 0; j < ENC_AHEAD; ++j) request(ring[j]);
+  }
   for (int c = C - 1; c >= 0; --c) {
     const int len = cdf_len[c];
     const int32_t max_value = len - 2;
@@ -194,18 +215,7 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
     if (!live) continue;  // idle lanes (last block only) sit out the coding loop: no per-symbol predication for them
     // symbols are fetched one batch ahead, so their load latency hides under the coding of the current batch
     int32_t sv_next[SYM_BATCH];
-    // stream-major symbols (ssi == 1: licos_conv5x5s2_f16_symbols writes them so): a batch is the lane's own 32 contiguous
-    // bytes - two 16-byte loads instead of eight dwords at a stride; the lines a wave touches (64 x 128 B) stay in the
-    // CU's cache for the four batches that use them
     auto fetch = [&](int p1, int32_t (&dst)[SYM_BATCH]) {
-      if (vec_ok && p1 >= SYM_BATCH) {
-        static_assert(SYM_BATCH == 8, "two int4 per batch");
-        const int4 *q = reinterpret_cast<const int4 *>(sp + (size_t)c * plane + (p1 - SYM_BATCH));
-        const int4 lo = q[0], hi = q[1];
-        dst[0] = hi.w; dst[1] = hi.z; dst[2] = hi.y; dst[3] = hi.x;
-        dst[4] = lo.w; dst[5] = lo.z; dst[6] = lo.y; dst[7] = lo.x;
-        return;
-      }
 #pragma unroll
       for (int k = 0; k < SYM_BATCH; ++k)
         dst[k] = (p1 - 1 - k >= 0) ? sp[(size_t)((size_t)c * plane + (p1 - 1 - k)) * ssi] : 0;
@@ -261,6 +271,19 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
         code_symbol(k);
       }
     };
+    if (vec_ok) {
+      static_assert(SYM_BATCH == 8, "two int4 per batch");
+      for (int jj = 0; jj < plane / SYM_BATCH; jj += ENC_AHEAD) {
+#pragma unroll
+        for (int j = 0; j < ENC_AHEAD; ++j) {
+          const int4 lo = ring[j][0], hi = ring[j][1];
+          const int32_t sv[SYM_BATCH] = {hi.w, hi.z, hi.y, hi.x, lo.w, lo.z, lo.y, lo.x};
+          request(ring[j]);
+          code_batch(std::true_type{}, sv, SYM_BATCH);
+        }
+      }
+      continue;
+    }
     fetch(plane, sv_next);
     int p1 = plane;
     for (; p1 >= SYM_BATCH; p1 -= SYM_BATCH) {

@@ -106,9 +106,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void kloop(const half8 *__re
 #pragma unroll
         for (int k = 0; k < PPW + WPW; ++k) piece(k);
       }
+      // DMA == 9 (round 5): the UPPER BOUND of phase-shared patch staging - the patch of a cin chunk requested once for all
+      // four output phases (every 4th step), the weights every step.  Not realisable in the product as it stands: the four
+      // phases' accumulators of a 16 x 32 tile are 512 registers per lane (or the 8 chunks' patches 166 KB of LDS).
+      if (DMA == 9) {
+#pragma unroll
+        for (int k = 0; k < PPW + WPW; ++k)
+          if (k >= PPW || (st & 3) == 0) piece(k);
+      }
       // DMA >= 2: one piece every DMA / 2 items (an item = one A fragment's MFMAs), waves of the upper half (the SIMD
       // partners) one slot later (DMA odd: same slot)
-      const int off = (DMA >= 2 && !(DMA & 1) && wave >= WAVES / 2) ? 1 : 0;
+      const int off = (DMA >= 2 && DMA != 9 && !(DMA & 1) && wave >= WAVES / 2) ? 1 : 0;
       const half8 *sp = buf, *sw = buf + I::PATCH_PIECES * 64;
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void kloop(const half8 *__re
         for (int n = 0; n < NT; ++n) b[n] = sp[base[n] + toff];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          if (DMA >= 2) {
+          if (DMA >= 2 && DMA != 9) {
             constexpr int SP = (DMA / 2) < 1 ? 1 : DMA / 2;
             const int item = t * MT + m - off;
             if (item >= 0 && item % SP == 0 && item / SP < PPW + WPW) piece(item / SP);
@@ -247,6 +255,7 @@ int main(int argc, char **argv) {
       {"A +DMA 1 piece / item, partners +1    ", launch<false, 8, 2>}, {"A +DMA 1 piece / item, same slot      ", launch<false, 8, 3>},
       {"A +DMA 1 piece / 2 items, partners +1 ", launch<false, 8, 4>}, {"A +DMA 1 piece / 2 items, same slot   ", launch<false, 8, 5>},
       {"A +DMA 1 piece / 3 items, partners +1 ", launch<false, 8, 6>}, {"A +DMA 1 piece / 4 items, partners +1 ", launch<false, 8, 8>},
+      {"A +DMA weights / step, patch / 4 steps", launch<false, 8, 9>},
   };
   const int NV = sizeof(vs) / sizeof(vs[0]);
   std::vector<std::vector<float>> ms(NV);

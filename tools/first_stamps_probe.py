@@ -109,14 +109,11 @@ def run_first(B):
 
 
 SWEEP = [
-    ({}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_nt.so"}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE.so"}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE_nt.so"}, ["first", "4096"]),
-    ({}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_nt.so"}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE.so"}, ["first", "4096"]),
-    ({"LICOS_HIP_SO": "build/ab/liblicos_first_prioE_nt.so"}, ["first", "4096"]),
+    ({"LICOS_FIRST16_DUO": "1"}, ["first16", "1024"]),
+    ({"LICOS_FIRST16_DUO": "1", "LICOS_HIP_SO": "build/ab/liblicos_f16d_young1.so"}, ["first16", "1024"]),
+    ({"LICOS_FIRST16_DUO": "1", "LICOS_HIP_SO": "build/ab/liblicos_f16d_young2.so"}, ["first16", "1024"]),
+    ({"LICOS_FIRST16_DUO": "1", "LICOS_HIP_SO": "build/ab/liblicos_f16d_young1_stamps.so"}, ["first16", "1024"]),
+    ({"LICOS_FIRST16_DUO": "1"}, ["first16", "1024"]),
 ]
 
 

@@ -59,7 +59,8 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
     # fp16 transforms: the quantiser rides in the last analysis stage's epilogue (licos_conv5x5s2_f16_symbols) and writes the
     # symbols stream-major, [stream][position], which the plane encoder reads as each lane's own 32-byte runs - no fp32
     # latent in memory and no transposing quantise kernel.  The fp32 parity path keeps the separate kernel.
-    fused = (not records and config.eb_stream_major and net.precision == "fp16" and not getattr(net.g_a, "fp32_only", False)
+    stream_major = config.eb_stream_major and not records
+    fused = (stream_major and net.precision == "fp16" and not getattr(net.g_a, "fp32_only", False)
              and engine.symbols_fusable(net.g_a))
     queued = []  # every tensor another stream touches stays referenced here until its chunk is drained
     for (s0, n) in chunks(n_dev, chunk):
@@ -71,24 +72,29 @@ def compress_chunked(net, x, chunk=1024, cap_words=None, sym16=None):
         if shape is None:
             shape = tuple(y.shape[-2:])
             nsym, plane = y[0].numel(), y[0, 0].numel()
-            if not records and not fused:
+            if not records and not stream_major:
                 sym = torch.empty((nsym, n_dev), device=dev, dtype=torch.int32)
             if cap_words is None:
                 cap_words = nsym // 2 + 64
         if records:
             keep = ops.eb_encode_prepare(y.contiguous(), med, table, cdf_len, offset, cdf.shape[1])
         else:
-            if not fused:
+            if fused:
+                keep = y
+            elif stream_major:  # (the fp32 parity path: its own quantise kernel, the same stream-major symbols for the encoder)
+                keep = torch.empty((n, nsym), device=dev, dtype=torch.int32)
+                ops.eb_quantize(y, med, "symbols", symbols=keep, sym_stride_b=nsym, sym_stride_i=1)
+            else:
                 ops.eb_quantize(y, med, "symbols", symbols=sym, sym_stride_b=1, sym_stride_i=n_dev, sym_offset=s0)
-            keep = y
+                keep = y
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
             if records:
                 words, nwords, status = ops.rans_encode_records(keep[0], keep[1], cap_words)
-            elif fused:
-                words, nwords, status = ops.rans_encode_batch(y, nsym, 1, nsym, plane, cdf, cdf_len, offset, table, cap_words, n)
+            elif stream_major:
+                words, nwords, status = ops.rans_encode_batch(keep, nsym, 1, nsym, plane, cdf, cdf_len, offset, table, cap_words, n)
             else:
                 words, nwords, status = ops.rans_encode_batch(sym, 1, n_dev, nsym, plane, cdf, cdf_len, offset, table, cap_words,
                                                               n, sym_offset=s0)

@@ -189,21 +189,35 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
   // (1.2 us) does not cover: with one batch of look-ahead the launch took 15.9 ms instead of 7.1 (round 5, first form).
   constexpr int ENC_AHEAD = 4;
   const bool vec_ok = ssi == 1 && (plane % (SYM_BATCH * ENC_AHEAD)) == 0 && (ssb & 3) == 0 && (reinterpret_cast<uintptr_t>(symbols) & 15) == 0;  // (uniform)
-  int4 ring[ENC_AHEAD][2];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));  // (a native vector: asm operands must be register values)
+  i32x4 ring[ENC_AHEAD][2];
   long g_next = 0;  // next batch to request: batch g is positions n - 8 (g + 1) .. n - 8 g - 1 of the stream
   const long n_total = (long)C * plane;
-  auto request = [&](int4 (&slot)[2]) {
-    const long pos = n_total - (long)SYM_BATCH * (g_next + 1);
-    if (pos >= 0) {
-      const int4 *q = reinterpret_cast<const int4 *>(sp + pos);
-      slot[0] = q[0];
-      slot[1] = q[1];
-    }
+  // The requests are inline assembly with a counted wait in front of their use: left to the compiler, the loop-carried
+  // ring makes it wait for vmcnt(0) once per four batches - the 32 unconditional word stores of those batches included, a
+  // full store round trip per 32 symbols.  Behind slot j's request come three more batches of
+  // 2 loads + 8 stores before the slot is used again (the slot is re-requested right behind its own batch): s_waitcnt
+  // vmcnt(30) covers exactly the request (escapes only add
+  // stores; the ragged end of a stream falls back to vmcnt(0)).  Past the front of the stream the address is clamped:
+  // every request is issued, whatever its position.
+  auto request = [&](i32x4 (&slot)[2]) {
+    long pos = n_total - (long)SYM_BATCH * (g_next + 1);
+    pos = pos < 0 ? 0 : pos;
+    const i32x4 *q = reinterpret_cast<const i32x4 *>(sp + pos);
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(slot[0]), "=&v"(slot[1]) : "v"(q) : "memory");
     ++g_next;
   };
+  // (ONE form of the wait inside the loop: with two, the compiler copied the slot's registers into the statement's operand
+  // registers in front of the un-counted one - before the data had landed)
+  auto landed = [&](i32x4 (&slot)[2]) { asm volatile("s_waitcnt vmcnt(30)" : "+v"(slot[0]), "+v"(slot[1])::"memory"); };
   if (vec_ok && live) {
 #pragma unroll
     for (int j = 0; j < ENC_AHEAD; ++j) request(ring[j]);
+    // the first pass over the ring has fewer operations behind its requests than the loop's counted wait assumes: they land here
+    static_assert(ENC_AHEAD == 4, "eight tied operands");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
+                   "+v"(ring[3][1])::"memory");
   }
   for (int c = C - 1; c >= 0; --c) {
     const int len = cdf_len[c];
@@ -276,10 +290,13 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
       for (int jj = 0; jj < plane / SYM_BATCH; jj += ENC_AHEAD) {
 #pragma unroll
         for (int j = 0; j < ENC_AHEAD; ++j) {
-          const int4 lo = ring[j][0], hi = ring[j][1];
+          landed(ring[j]);
+          const i32x4 lo = ring[j][0], hi = ring[j][1];
           const int32_t sv[SYM_BATCH] = {hi.w, hi.z, hi.y, hi.x, lo.w, lo.z, lo.y, lo.x};
-          request(ring[j]);
           code_batch(std::true_type{}, sv, SYM_BATCH);
+          // (re-requested BEHIND the batch's coding, three batches ahead of its next use: requested in front of it the
+          // compiler has to move the slot's old values out of the way, and it did so in front of the wait)
+          request(ring[j]);
         }
       }
       continue;
@@ -294,6 +311,13 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
       code_batch(std::true_type{}, sv, SYM_BATCH);
     }
     if (p1 > 0) code_batch(std::false_type{}, sv_next, p1);
+  }
+  if (vec_ok && live) {
+    // the requests that ran past the front of the stream are still in flight: they land before the ring's registers may
+    // become anything else (the same hazard as in rans_encode_records_regs_kernel, csrc/rans_gc.hip)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
+                   "+v"(ring[3][1])::"memory");
   }
   if (live) {
     sink.put((uint32_t)(x >> 32));

@@ -19,6 +19,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "rans_image.hpp"
 
@@ -198,8 +200,21 @@ struct WordSink {
   const uint32_t *base;  // row 0 of this stream (wave-uniform part folded in by the compiler or not - a 64-bit pair either way)
   uint32_t off;          // byte offset of the next free row; 0 = the dump row
   uint32_t stride;       // bytes between two rows
+#ifdef LICOS_GC_DEBUG
+  uint32_t limit = 0xFFFFFFFFu;
+  int32_t *dbg = nullptr;
+#endif
   __device__ inline void store(uint32_t w) const {
-    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(w), "s"(base) : "memory");
+#ifdef LICOS_GC_DEBUG
+    if (off >= limit) {
+      if (dbg) atomicOr(dbg, 4);
+      return;
+    }
+#endif
+    // (the base through an s_mov: an SGPR the allocator brings back from a VGPR lane with v_readlane must not be read by a
+    // vector-memory instruction within five wait states, and nothing inside an asm statement is padded)
+    uint64_t base_copy;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(base_copy) : "v"(off), "v"(w), "s"(base) : "memory");
   }
   __device__ inline void claim(bool emit) {
     const uint32_t dec = emit ? stride : 0u;
@@ -223,6 +238,166 @@ constexpr int ENC_BATCH = 8, ENC_DEPTH = 8, ENC_AHEAD = 4;  // records are reque
 // operations (each batch issues ENC_BATCH request pieces and at least ENC_BATCH stores) waits for that request alone.
 // (The first version fetched records into registers and let the compiler place the waits: `vmcnt(0)` at every batch,
 // i.e. a full round trip of the stores just issued per 8 symbols - 235 ns per symbol, most of it that wait.)
+// Round 5: the records in REGISTERS instead of an LDS ring.  An LDS-DMA request costs its wave 80 - 100 cycles of issue (M0
+// juggling, the instruction itself: in-kernel stamps of mfma_first16.hip), one per symbol here - a quarter of the ~330 cycles
+// a symbol took; a plain 16-byte load per lane and symbol costs a tenth of that and needs no ds_read behind it.  Four
+// batches of eight records (128 VGPRs - the kernel has the file to itself) are in flight; the loads are inline assembly
+// with a counted wait in front of their use: behind a batch's request (issued right behind its own coding, so that the
+// slot's old values need no copy) come three batches of 8 loads + at least 8 stores - s_waitcnt vmcnt(48).  Requests past
+// the front of the stream re-read record 0 (never coded): every batch issues its eight loads whatever its position.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(const uint4 *__restrict__ rec, const int32_t *__restrict__ aux,
+                                                                              long n, uint32_t *__restrict__ words, int cap_words,
+                                                                              int32_t *__restrict__ nwords, int32_t *__restrict__ status,
+                                                                              int B) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_b0 = (blockIdx.x * WAVES + wave) * 64;
+  if (wave_b0 >= B) return;
+  const bool live = wave_b0 + lane < B;
+  const int b = live ? wave_b0 + lane : B - 1;  // idle lanes shadow the last stream; their stores go to the same rows with the same words
+  const int32_t *ap = aux + b;
+  const long nbat = (n + ENC_BATCH - 1) / ENC_BATCH;
+  const unsigned voff = (unsigned)b * 16u;
+  const uint64_t row_bytes = (uint64_t)B * 16u;
+  static_assert(ENC_BATCH == 8 && ENC_AHEAD == 4, "eight loads per request, vmcnt(48) = three batches of 8 loads + 8 stores");
+  u32x4 ring[ENC_AHEAD][ENC_BATCH];
+  auto request = [&](u32x4 (&slot)[ENC_BATCH], long t) {
+    // records n - 1 - 8 t - k, k = 0 .. 7: scalar row bases (wave-uniform), one 32-bit lane offset
+    long i0 = n - 1 - t * ENC_BATCH;
+    uint64_t base[ENC_BATCH];
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) {
+      const long i = i0 - k < 0 ? 0 : i0 - k;
+      base[k] = reinterpret_cast<uint64_t>(rec) + (uint64_t)i * row_bytes;
+    }
+#ifdef LICOS_GC_DEBUG  // (diagnostic builds: every address against the buffer before it is used)
+    {
+      const uint64_t lo = reinterpret_cast<uint64_t>(rec), hi = lo + (uint64_t)n * row_bytes;
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < ENC_BATCH; ++k) bad = bad || base[k] + voff < lo || base[k] + voff + 16 > hi;
+      if (__any(bad)) {
+        if (bad) {
+          atomicOr(status, 2);
+          atomicMax(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)t);
+          atomicMax(reinterpret_cast<unsigned long long *>(status + 4), base[0] - lo);
+        }
+#pragma unroll
+        for (int k = 0; k < ENC_BATCH; ++k) base[k] = lo;
+      }
+    }
+#endif
+#ifdef LICOS_GC_ENC_VADDR  // (A/B: 64-bit vector addresses instead of scalar base + lane offset)
+    const unsigned char *a8[ENC_BATCH];
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) a8[k] = reinterpret_cast<const unsigned char *>(base[k]) + voff;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %9, off\n\tglobal_load_dwordx4 %2, %10, off\n\tglobal_load_dwordx4 %3, %11, off\n\t"
+        "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %13, off\n\tglobal_load_dwordx4 %6, %14, off\n\tglobal_load_dwordx4 %7, %15, off"
+        : "=&v"(slot[0]), "=&v"(slot[1]), "=&v"(slot[2]), "=&v"(slot[3]), "=&v"(slot[4]), "=&v"(slot[5]), "=&v"(slot[6]), "=&v"(slot[7])
+        : "v"(a8[0]), "v"(a8[1]), "v"(a8[2]), "v"(a8[3]), "v"(a8[4]), "v"(a8[5]), "v"(a8[6]), "v"(a8[7])
+        : "memory");
+#else
+    asm volatile(
+        "global_load_dwordx4 %0, %8, %9\n\tglobal_load_dwordx4 %1, %8, %10\n\tglobal_load_dwordx4 %2, %8, %11\n\tglobal_load_dwordx4 %3, %8, %12\n\t"
+        "global_load_dwordx4 %4, %8, %13\n\tglobal_load_dwordx4 %5, %8, %14\n\tglobal_load_dwordx4 %6, %8, %15\n\tglobal_load_dwordx4 %7, %8, %16"
+        : "=&v"(slot[0]), "=&v"(slot[1]), "=&v"(slot[2]), "=&v"(slot[3]), "=&v"(slot[4]), "=&v"(slot[5]), "=&v"(slot[6]), "=&v"(slot[7])
+        : "v"(voff), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]), "s"(base[4]), "s"(base[5]), "s"(base[6]), "s"(base[7])
+        : "memory");
+#endif
+  };
+  auto landed48 = [&](u32x4 (&slot)[ENC_BATCH]) {
+    asm volatile("s_waitcnt vmcnt(48)"
+                 : "+v"(slot[0]), "+v"(slot[1]), "+v"(slot[2]), "+v"(slot[3]), "+v"(slot[4]), "+v"(slot[5]), "+v"(slot[6]), "+v"(slot[7])::"memory");
+  };
+  auto landed0 = [&](u32x4 (&slot)[ENC_BATCH]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(slot[0]), "+v"(slot[1]), "+v"(slot[2]), "+v"(slot[3]), "+v"(slot[4]), "+v"(slot[5]), "+v"(slot[6]), "+v"(slot[7])::"memory");
+  };
+  WordSink sink{words, ((uint32_t)cap_words * (uint32_t)B + (uint32_t)b) * 4u, (uint32_t)B * 4u};
+#ifdef LICOS_GC_DEBUG
+  sink.limit = ((uint32_t)cap_words + 1u) * (uint32_t)B * 4u;
+  sink.dbg = status;
+#endif
+  uint64_t x = RANS_L;
+  auto code_symbol = [&](const u32x4 r) {
+    const uint32_t cfreq = r.w & 0xFFFFu;  // 2^16 - freq
+    const uint32_t shift = (r.w >> 16) & 0x7FFFu;
+    const uint64_t rcp = ((uint64_t)r.y << 32) | r.x;
+    const bool emit = (uint32_t)(x >> 32) + (cfreq << 15) >= 0x80000000u;
+    sink.put_if(emit, (uint32_t)x);
+    x = emit ? (x >> 32) : x;
+    const uint64_t q = __umul64hi(x, rcp) >> shift;
+    x = x + r.z + q * (uint64_t)cfreq;
+  };
+  auto code_escape = [&](long i) {
+#ifdef LICOS_GC_DEBUG
+    if (i < 0 || i >= n) {
+      atomicOr(status, 8);
+      return;
+    }
+#endif
+    const uint32_t raw = (uint32_t)ap[(size_t)i * B];
+    int nbyp = 0;
+    while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
+    for (int j = nbyp - 1; j >= 0; --j) put_bits4(x, sink, (raw >> (j * 4)) & 15u);
+    put_bits4(x, sink, (uint32_t)nbyp);
+  };
+  // batch t from `cur`: ONE basic block of eight chained symbols when no lane of the wave carries an escape
+  auto code_batch = [&](const u32x4 (&cur)[ENC_BATCH], long t) {
+    const long i1 = n - t * ENC_BATCH;  // symbols i1 - 1 ... i1 - ENC_BATCH
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) flags |= cur[k].w;
+    if (__builtin_expect(i1 >= ENC_BATCH && !__any((flags & REC_ESCAPE) != 0), 1)) {
+#pragma unroll
+      for (int k = 0; k < ENC_BATCH; ++k) code_symbol(cur[k]);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < ENC_BATCH; ++k) {
+      if (i1 - 1 - k < 0) break;
+      if ((cur[k].w & REC_ESCAPE) != 0) code_escape(i1 - 1 - k);
+      code_symbol(cur[k]);
+    }
+  };
+  // prologue: four batches requested, landed before the loop (the first pass has fewer operations behind its requests
+  // than the loop's counted wait assumes)
+#pragma unroll
+  for (int j = 0; j < ENC_AHEAD; ++j) request(ring[j], j);
+#pragma unroll
+  for (int j = 0; j < ENC_AHEAD; ++j) landed0(ring[j]);
+  // whole groups of four FULL batches: counted waits; the ragged end (the last group, whose last batch may be short and
+  // issue fewer stores than the count assumes) waits for everything
+  const long full_groups = (n / ENC_BATCH) / ENC_AHEAD;
+  long t = 0;
+  for (long g = 0; g < full_groups; ++g) {
+#pragma unroll
+    for (int j = 0; j < ENC_AHEAD; ++j, ++t) {
+      landed48(ring[j]);
+      code_batch(ring[j], t);
+      request(ring[j], t + ENC_AHEAD);
+    }
+  }
+  // The requests that ran past the front of the stream are still in flight: they must land before the compiler may give
+  // the ring's registers to anything else - an address of the epilogue below, say, which a late load would overwrite (found
+  // as a memory fault at >= 1024 streams, where the loads are slow enough to land behind the loop).
+#pragma unroll
+  for (int j = 0; j < ENC_AHEAD; ++j) landed0(ring[j]);
+#pragma unroll
+  for (int j = 0; j < ENC_AHEAD; ++j, ++t) {
+    if (t < nbat) code_batch(ring[j], t);
+  }
+  if (live) {
+    sink.put((uint32_t)(x >> 32));
+    sink.put((uint32_t)x);
+    const uint32_t row = sink.off / sink.stride;
+    nwords[b] = cap_words - (int)row;
+    if (row == 0) atomicOr(status, 1);
+  }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_kernel(const uint4 *__restrict__ rec, const int32_t *__restrict__ aux,
                                                                          long n, uint32_t *__restrict__ words, int cap_words,
@@ -846,6 +1021,16 @@ int licos_rans_encode_records(const void *rec, const int32_t *aux, long n, uint3
     LICOS_LAUNCH_CHECK();
     return LICOS_OK;
   };
+  static const bool regs = [] { const char *e = getenv("LICOS_GC_ENC_REGS"); return !e || atoi(e) != 0; }();  // (A/B: 0 = the LDS-DMA ring)
+  if (regs) {
+    auto launch_r = [&](auto kern, int waves) -> int {
+      hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * waves)), dim3(64 * waves), 0, as_stream(stream), static_cast<const uint4 *>(rec), aux, n, words,
+                         cap_words, nwords, status, B);
+      LICOS_LAUNCH_CHECK();
+      return LICOS_OK;
+    };
+    return B > 64 ? launch_r(rans_encode_records_regs_kernel<2>, 2) : launch_r(rans_encode_records_regs_kernel<1>, 1);
+  }
   return B > 64 ? launch(rans_encode_records_kernel<2>, 2) : launch(rans_encode_records_kernel<1>, 1);
 }
 

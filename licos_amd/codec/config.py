@@ -44,7 +44,7 @@ class CodecConfig:
     zero_copy: bool = False        # LICOS_ZERO_COPY=1: quantise / dequantise kernels store to / load from page-locked memory (A/B)
     # -- which device coder (A/B) -----------------------------------------------------------------------------------------
     eb_records: bool = False       # LICOS_EB_RECORDS=1: record encoder for the entropy bottleneck
-    eb_image: bool = True          # LICOS_EB_IMAGE=0: the plane decoder of rans.hip instead of the image decoder
+    eb_image: bool = False         # LICOS_EB_IMAGE=1: the image decoder of rans_gc.hip (round 4) instead of the plane decoder of rans.hip
     eb_stream_major: bool = True   # LICOS_EB_STREAM_MAJOR=0: device plane coder on [position][stream] symbols through the transposing kernels (A/B)
 
     @classmethod

@@ -262,7 +262,10 @@ def decompress_chunked(net, strings, shape, chunk=1024):
     sec = Section()
     sec.mark("d.start")
     n_dev = B - n_host
-    sym = torch.empty((nsym, n_dev), device=dev, dtype=torch.int32) if n_dev else None  # device-decoded tiles, [position][stream]
+    # device-decoded tiles: [stream][position] from the round-5 plane decoder (16-byte stores from registers), [position][stream]
+    # from the image decoder
+    stream_major = config.eb_stream_major and not config.eb_image
+    sym = (torch.empty((n_dev, nsym) if stream_major else (nsym, n_dev), device=dev, dtype=torch.int32)) if n_dev else None
     status = torch.zeros(1, device=dev, dtype=torch.int32)
     image = eb.coder_image() if config.eb_image else None  # the image decoder (csrc/rans_gc.hip), channel pattern as shared rows
     rows = eb.channel_rows(plane) if image is not None else None
@@ -322,6 +325,9 @@ def decompress_chunked(net, strings, shape, chunk=1024):
             if image is not None:
                 ops.rans_decode_image(data, byte_off, rows, nsym, image[0], image[1], sym, 1, n_dev, n, status=status,
                                       sym_offset=s0 - n_host, rows_shared=True)
+            elif stream_major:
+                ops.rans_decode_batch(data, byte_off, nsym, 1, nsym, plane, cdf, cdf_len, offset, sym, n, sym_offset=(s0 - n_host) * nsym,
+                                      status=status, off_offset=0)
             else:
                 ops.rans_decode_batch(data, byte_off, 1, n_dev, nsym, plane, cdf, cdf_len, offset, sym, n, sym_offset=s0 - n_host,
                                       status=status, off_offset=0)
@@ -355,7 +361,10 @@ def decompress_chunked(net, strings, shape, chunk=1024):
     def synthesise_device_pieces():
         for (s0, n, _), ev in zip(pieces, events):
             main.wait_event(ev)
-            synthesise(s0, n, sym, 1, n_dev, sym_offset=s0 - n_host)
+            if stream_major:
+                synthesise(s0, n, sym, nsym, 1, sym_offset=(s0 - n_host) * nsym)
+            else:
+                synthesise(s0, n, sym, 1, n_dev, sym_offset=s0 - n_host)
 
     # The host's tiles, sub-chunk by sub-chunk: decode (this thread blocks, the device decoders run), upload, synthesise.
     # When the call has device pieces as well, the host's tiles are synthesised on a stream of their own and the device

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <type_traits>
+#include <utility>
 
 #include "licos_hip.h"
 
@@ -34,6 +36,18 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 constexpr int WAVE = 64;
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) - for bodies that need the index as a
+// constant expression (sched_group_barrier sizes)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 
 // Raises a kernel's dynamic-LDS limit to `bytes` on the CURRENT device, once per (device, kernel): the library is
 // re-entrant per (device, stream) - a process-wide "already set" flag would skip the other devices of a

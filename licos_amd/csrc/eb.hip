@@ -454,7 +454,9 @@ __global__ __launch_bounds__(256) void eb_symbols16_kernel(const float *__restri
 
 // dequantise to fp16 blk16 [B][C16][HW][16]: a block owns 16 channels x 64 positions of one stream - 8-byte reads along
 // the positions, transposed through LDS, 16-byte writes of 8 channels per position
-__global__ __launch_bounds__(256) void eb_dequantize16_blk_kernel(const int16_t *__restrict__ sym, const float *__restrict__ medians,
+// (S = int16_t: the host coder's symbols; S = int32_t: the device decoder's stream-major ones, round 5 - `ssb`: symbols per stream row)
+template <typename S>
+__global__ __launch_bounds__(256) void eb_dequantize16_blk_kernel(const S *__restrict__ sym, long ssb, const float *__restrict__ medians,
                                                                   _Float16 *__restrict__ y_blk, int C, int HW) {
   __shared__ _Float16 tile[64][16 + 8];
   const int C16 = (C + 15) / 16;
@@ -462,10 +464,11 @@ __global__ __launch_bounds__(256) void eb_dequantize16_blk_kernel(const int16_t 
   {
     const int ch = threadIdx.x >> 4, qd = threadIdx.x & 15;
     const int c = c16 * 16 + ch;
-    short4 q = make_short4(0, 0, 0, 0);
+    typedef S S4 __attribute__((ext_vector_type(4)));
+    S4 q = {0, 0, 0, 0};
     float md = 0.f;
     if (c < C) {
-      q = *reinterpret_cast<const short4 *>(sym + ((size_t)b * C + c) * HW + p0 + 4 * qd);
+      q = *reinterpret_cast<const S4 *>(sym + (size_t)b * ssb + (size_t)c * HW + p0 + 4 * qd);
       md = medians[c];
     }
     tile[4 * qd + 0][ch] = c < C ? (_Float16)((float)q.x + md) : (_Float16)0.f;
@@ -745,6 +748,14 @@ int licos_eb_dequantize(const int32_t *symbols, long ssb, long ssi, const float 
     LICOS_LAUNCH_CHECK();
     return LICOS_OK;
   }
+  // stream-major symbols (what the round-5 plane decoder writes, 16 bytes per lane and four symbols): the 16-bit form's kernel
+  if (ssi == 1 && !y_nchw && (H * W) % 64 == 0 && B <= 65535 && (C + 15) / 16 <= 65535 && (ssb & 3) == 0 && ((uintptr_t)symbols & 15) == 0 &&
+      ((uintptr_t)y_blk16 & 15) == 0) {
+    hipLaunchKernelGGL(eb_dequantize16_blk_kernel<int32_t>, dim3(H * W / 64, (C + 15) / 16, B), dim3(256), 0, as_stream(stream), symbols, ssb,
+                       medians, static_cast<_Float16 *>(y_blk16), C, H * W);
+    LICOS_LAUNCH_CHECK();
+    return LICOS_OK;
+  }
   if (ssb == 1 && B <= 65535 * 64) {
     const long n = (long)C * H * W;
     hipLaunchKernelGGL(eb_dequantize_T_kernel, dim3((unsigned)((n + 63) / 64), (B + 63) / 64), dim3(256), 0, as_stream(stream),
@@ -804,8 +815,8 @@ int licos_eb_dequantize16(const int16_t *symbols, const float *medians, float *y
   if (y_blk16) {
     LICOS_REQUIRE(HW % 64 == 0 && B <= 65535 && (C + 15) / 16 <= 65535 && ((uintptr_t)y_blk16 & 15) == 0 && ((uintptr_t)symbols & 7) == 0,
                   "eb_dequantize16: the blk16 form needs H * W to be a multiple of 64 and aligned buffers");
-    hipLaunchKernelGGL(eb_dequantize16_blk_kernel, dim3(HW / 64, (C + 15) / 16, B), dim3(256), 0, as_stream(stream), symbols, medians,
-                       static_cast<_Float16 *>(y_blk16), C, HW);
+    hipLaunchKernelGGL(eb_dequantize16_blk_kernel<int16_t>, dim3(HW / 64, (C + 15) / 16, B), dim3(256), 0, as_stream(stream), symbols,
+                       (long)C * HW, medians, static_cast<_Float16 *>(y_blk16), C, HW);
     LICOS_LAUNCH_CHECK();
   }
   if (y_nchw) {

@@ -62,17 +62,6 @@ struct ConvStepGeom {
   static_assert(PATCH_GRAN % 64 == 0, "patch must be a whole number of wave-wide LDS-DMA pieces");
 };
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) - for bodies that need the index as a
-// constant expression (sched_group_barrier sizes)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 // XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8
 // XCDs, each with a private L2, so linear ids l and l+8 share an L2.  The grid is 1-D over B images x
 // `per_image` work items; this remap hands each XCD whole images (8 images in flight, one per XCD, their

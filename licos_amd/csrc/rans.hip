@@ -7,6 +7,7 @@
 // symbols in reverse (the encoder emits words back to front).  Words are staged in an
 // interleaved scratch [word][stream] so that lanes advancing in lock-step write coalesced.
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace licos {
@@ -189,35 +190,54 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
   // (1.2 us) does not cover: with one batch of look-ahead the launch took 15.9 ms instead of 7.1 (round 5, first form).
   constexpr int ENC_AHEAD = 4;
   const bool vec_ok = ssi == 1 && (plane % (SYM_BATCH * ENC_AHEAD)) == 0 && (ssb & 3) == 0 && (reinterpret_cast<uintptr_t>(symbols) & 15) == 0;  // (uniform)
-  typedef int i32x4 __attribute__((ext_vector_type(4)));  // (a native vector: asm operands must be register values)
-  i32x4 ring[ENC_AHEAD][2];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   long g_next = 0;  // next batch to request: batch g is positions n - 8 (g + 1) .. n - 8 g - 1 of the stream
   const long n_total = (long)C * plane;
   // The requests are inline assembly with a counted wait in front of their use: left to the compiler, the loop-carried
   // ring makes it wait for vmcnt(0) once per four batches - the 32 unconditional word stores of those batches included, a
-  // full store round trip per 32 symbols.  Behind slot j's request come three more batches of
-  // 2 loads + 8 stores before the slot is used again (the slot is re-requested right behind its own batch): s_waitcnt
-  // vmcnt(30) covers exactly the request (escapes only add
-  // stores; the ragged end of a stream falls back to vmcnt(0)).  Past the front of the stream the address is clamped:
-  // every request is issued, whatever its position.
-  auto request = [&](i32x4 (&slot)[2]) {
+  // full store round trip per 32 symbols.  Behind slot j's request come three more batches of 2 loads + 8 stores before
+  // the slot is used again (the slot is re-requested right behind its own batch): s_waitcnt vmcnt(30) covers exactly the
+  // request (escapes only add stores).  Past the front of the stream the address is clamped: every request is issued,
+  // whatever its position.
+  //
+  // The ring lives in NAMED registers, v[200:231], that no C++ value ever occupies: a request only clobbers them, and the
+  // statement that waits is the one that DEFINES the slot's values (physical-register output constraints).  The first form
+  // of this ring (round 5, commit "plane encoder's requests as counted asm loads") passed the slot through "+v" operands of
+  // the wait; the register allocator is free to give such an operand another register and COPY the ring's register into it
+  // in front of the statement - in front of the wait, that is: a copy of data still in flight, right whenever the load
+  // happened to be back already and wrong (56 streams of 4096 in one run of tools/eb_coder_bench.py) whenever it was not.
+  // Nothing the compiler can see holds a value that is still on its way now; tests/test_host.py checks in the shipped
+  // library's disassembly that these registers appear in the ring's own statements only.
+#define LICOS_ENC_RING_REQUEST(LO, HI)                                                                                            \
+  asm volatile("global_load_dwordx4 v[" #LO ":" #LO "+3], %0, off\n\tglobal_load_dwordx4 v[" #HI ":" #HI "+3], %0, off offset:16" \
+               :: "v"(q) : "memory", LICOS_ENC_RING_CLOBBER)
+#define LICOS_ENC_RING_CLOBBER                                                                                                      \
+  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", \
+      "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231"
+  auto request = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     long pos = n_total - (long)SYM_BATCH * (g_next + 1);
     pos = pos < 0 ? 0 : pos;
     const i32x4 *q = reinterpret_cast<const i32x4 *>(sp + pos);
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(slot[0]), "=&v"(slot[1]) : "v"(q) : "memory");
+    // (each statement names its own slot and declares the whole ring clobbered: nothing of the compiler's lives there)
+    if constexpr (j == 0) LICOS_ENC_RING_REQUEST(200, 204);
+    if constexpr (j == 1) LICOS_ENC_RING_REQUEST(208, 212);
+    if constexpr (j == 2) LICOS_ENC_RING_REQUEST(216, 220);
+    if constexpr (j == 3) LICOS_ENC_RING_REQUEST(224, 228);
     ++g_next;
   };
-  // (ONE form of the wait inside the loop: with two, the compiler copied the slot's registers into the statement's operand
-  // registers in front of the un-counted one - before the data had landed)
-  auto landed = [&](i32x4 (&slot)[2]) { asm volatile("s_waitcnt vmcnt(30)" : "+v"(slot[0]), "+v"(slot[1])::"memory"); };
+  auto landed = [&](auto jc, i32x4 &lo, i32x4 &hi) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j == 0) asm volatile("s_waitcnt vmcnt(30)" : "={v[200:203]}"(lo), "={v[204:207]}"(hi)::"memory");
+    if constexpr (j == 1) asm volatile("s_waitcnt vmcnt(30)" : "={v[208:211]}"(lo), "={v[212:215]}"(hi)::"memory");
+    if constexpr (j == 2) asm volatile("s_waitcnt vmcnt(30)" : "={v[216:219]}"(lo), "={v[220:223]}"(hi)::"memory");
+    if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(30)" : "={v[224:227]}"(lo), "={v[228:231]}"(hi)::"memory");
+  };
   if (vec_ok && live) {
-#pragma unroll
-    for (int j = 0; j < ENC_AHEAD; ++j) request(ring[j]);
+    static_assert(ENC_AHEAD == 4, "four named slots");
+    static_for<ENC_AHEAD>([&](auto jc) { request(jc); });
     // the first pass over the ring has fewer operations behind its requests than the loop's counted wait assumes: they land here
-    static_assert(ENC_AHEAD == 4, "eight tied operands");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
-                   "+v"(ring[3][1])::"memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (int c = C - 1; c >= 0; --c) {
     const int len = cdf_len[c];
@@ -288,16 +308,13 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
     if (vec_ok) {
       static_assert(SYM_BATCH == 8, "two int4 per batch");
       for (int jj = 0; jj < plane / SYM_BATCH; jj += ENC_AHEAD) {
-#pragma unroll
-        for (int j = 0; j < ENC_AHEAD; ++j) {
-          landed(ring[j]);
-          const i32x4 lo = ring[j][0], hi = ring[j][1];
+        static_for<ENC_AHEAD>([&](auto jc) {
+          i32x4 lo, hi;
+          landed(jc, lo, hi);
           const int32_t sv[SYM_BATCH] = {hi.w, hi.z, hi.y, hi.x, lo.w, lo.z, lo.y, lo.x};
           code_batch(std::true_type{}, sv, SYM_BATCH);
-          // (re-requested BEHIND the batch's coding, three batches ahead of its next use: requested in front of it the
-          // compiler has to move the slot's old values out of the way, and it did so in front of the wait)
-          request(ring[j]);
-        }
+          request(jc);  // (behind the batch's coding, three batches ahead of the slot's next use)
+        });
       }
       continue;
     }
@@ -313,11 +330,8 @@ __global__ __launch_bounds__(256) void rans_encode_plane_kernel(const int32_t *_
     if (p1 > 0) code_batch(std::false_type{}, sv_next, p1);
   }
   if (vec_ok && live) {
-    // the requests that ran past the front of the stream are still in flight: they land before the ring's registers may
-    // become anything else (the same hazard as in rans_encode_records_regs_kernel, csrc/rans_gc.hip)
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[3][0]),
-                   "+v"(ring[3][1])::"memory");
+    // the requests that ran past the front of the stream are still in flight: they land before the wave goes on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", LICOS_ENC_RING_CLOBBER);
   }
   if (live) {
     sink.put((uint32_t)(x >> 32));
@@ -504,6 +518,207 @@ __global__ __launch_bounds__(256) void rans_decode_plane_kernel(const uint8_t *_
   if (live && src.over) atomicOr(status, 1);
 }
 
+
+// ---- round 5: the same decoder, counted by INSTRUCTIONS ---------------------------------------------------------------
+// A coder wave has its SIMD to itself and the hardware issues it ONE instruction per four cycles, scalar ones, waits and
+// s_nop included (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): the kernel above spends ~60 instructions on a
+// symbol - 240 of its ~275 cycles are issue slots, not the 132-cycle dependent chain round 4 priced.  This form spends
+// 26:
+//  * the table record is 16 bytes { cdf[s], cdf[s+1], cdf[s+2], s + offset } read by one ds_read_b128: nothing to
+//    unpack, no SDWA forms (each of which cost an s_nop against the VCC hazard), the symbol's offset already added;
+//  * the table sits at LDS address 0 (an immediate, no base to add) and every wave's word ring on a 16-KB boundary, so a
+//    ring address is one v_and_or_b32 of the shifted read counter;
+//  * ONE rare-case test per symbol: buckets that can yield the escape symbol carry cdf[s+2] = 0, which sends them down the
+//    slow path that already exists for buckets of three or more symbols; that path (out of line) finishes the symbol
+//    itself - walk, state update, bypass nibbles;
+//  * freq * (x >> 16): one v_mad_u64_u32 for the low 32 bits of x >> 16 (carrying cf - lo as its addend) and a full-rate
+//    v_mad_u32_u24 for the 15 bits above, instead of two 64-bit multiplies and the moves between them;
+//  * reads past the end of a stream are detected ONCE, after the last symbol (the read counter only grows);
+//  * four symbols per pass of the loop; with stream-major symbols (ssi == 1, what codec.factorized asks for) they leave
+//    as one 16-byte store from registers - no LDS buffer, no flush loop.
+constexpr int DEC_LUT_BYTES = 16 << LUT_BITS;
+#define LICOS_OPAQUE(v) asm("" : "+v"(v))
+#ifdef LICOS_STAMPS  // (diagnostic builds via tools/ab_build.sh, never the product: s_memtime cycles of wave 0 of every workgroup)
+__device__ unsigned long long g_dec_stamps[4];
+#endif
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_cu32x4;
+typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CW, bool SM>
+__global__ __launch_bounds__(64 * CW) void rans_decode_plane4_kernel(const uint8_t *__restrict__ in, const int64_t *__restrict__ byte_off,
+                                                                     long ssb, long ssi, int C, int plane,
+                                                                     const int32_t *__restrict__ cdf, int cdf_stride,
+                                                                     const int32_t *__restrict__ cdf_len,
+                                                                     const int32_t *__restrict__ offset, int32_t *__restrict__ symbols,
+                                                                     int32_t *__restrict__ status, int B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int nthr = 64 * CW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // [table 16 KB][CW word rings, 16 KB each][CW symbol buffers, 4 KB each (strided output only)][the channel's cdf]
+  u32x4_t *s_lut = reinterpret_cast<u32x4_t *>(smem_raw);
+  uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem_raw + DEC_LUT_BYTES) + wave * (RING * 64);
+  int32_t *s_out = reinterpret_cast<int32_t *>(smem_raw + DEC_LUT_BYTES + CW * RING * 256) + wave * (SYM_BUF * 64);
+  uint32_t *s_cdf = reinterpret_cast<uint32_t *>(smem_raw + DEC_LUT_BYTES + CW * (RING + SYM_BUF) * 256);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem_raw;
+  if (lds0 != 0) {  // (the addresses below are absolute: never taken - the kernel has no static LDS in front of this block)
+    if (tid == 0) atomicOr(status, 4);
+    return;
+  }
+  const uint32_t ring_addr = DEC_LUT_BYTES + (uint32_t)wave * (RING * 256) + (uint32_t)lane * 4u;
+  const int b_raw = (blockIdx.x * CW + wave) * 64 + lane;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;
+  RingSource src;
+  src.init(reinterpret_cast<const uint32_t *>(in + byte_off[b]), (int)((byte_off[b + 1] - byte_off[b]) / 4), s_ring + lane,
+           reinterpret_cast<const uint32_t *>(byte_off));
+  uint32_t xlo = src.ring[0];
+  uint32_t xhi = src.ring[64];
+  src.rd = 2;
+  constexpr uint32_t LUT_MASK = ((1u << LUT_BITS) - 1u) << 4;
+  uint64_t rans_l = RANS_L;
+  asm volatile("" : "+s"(rans_l));
+#ifdef LICOS_STAMPS
+  unsigned long long st_tab = 0, st_loop = 0, st_prev = __builtin_amdgcn_s_memtime();
+#endif
+  int32_t *sp = symbols + (size_t)b * ssb;
+  for (int c = 0; c < C; ++c) {
+    const int len = cdf_len[c] < 2 ? 2 : cdf_len[c];
+    const int32_t max_value = len - 2;
+    const int32_t off = offset[c];
+    __syncthreads();
+    for (int e = tid; e < len; e += nthr) s_cdf[e] = (uint32_t)cdf[(size_t)c * cdf_stride + e];
+    __syncthreads();
+    // one record per value of the top LUT_BITS bits of cf; s = the largest symbol whose cdf[s] <= the bucket's first value
+    constexpr int KPL = (1 << LUT_BITS) / nthr;
+    {
+      const uint32_t key0 = (uint32_t)(tid * KPL) << (16 - LUT_BITS);
+      int lo = 0, hi = len - 1;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_cdf[mid] <= key0) lo = mid; else hi = mid;
+      }
+      for (int k = 0; k < KPL; ++k) {
+        const uint32_t key = (uint32_t)(tid * KPL + k) << (16 - LUT_BITS);
+        while (lo + 1 < len - 1 && s_cdf[lo + 1] <= key) ++lo;
+        // (a bucket that reaches the escape symbol within its first two symbols, or has no cdf[s + 2], is always "rare")
+        const uint32_t c2 = (lo + 1 >= max_value || lo + 2 > len - 1) ? 0u : s_cdf[lo + 2];
+        s_lut[tid * KPL + k] = u32x4_t{s_cdf[lo], s_cdf[lo + 1], c2, (uint32_t)(lo + off)};
+      }
+    }
+    __syncthreads();
+#ifdef LICOS_STAMPS
+    { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_tab += now_ - st_prev; st_prev = now_; }
+#endif
+    if (!live) continue;  // idle lanes (last block only) sit out the decoding loop
+
+    // one symbol; returns its value (offset included)
+    auto decode_one = [&]() -> int32_t {
+      const u32x4_t rec = *(lds_cu32x4 *)(uintptr_t)((xlo >> (16 - LUT_BITS - 4)) & LUT_MASK);
+      // the next stream word is read before it is known to be needed: its LDS latency runs beside the lookup's
+      const uint32_t w_next = *(lds_cu32 *)(uintptr_t)((((uint32_t)src.rd << 8) & (uint32_t)((RING - 1) << 8)) | ring_addr);
+      uint32_t Xlo = __builtin_amdgcn_alignbit(xhi, xlo, 16), Xhi = xhi >> 16;  // x >> 16
+      const bool adv = (xlo & 0xFFFFu) >= rec.y;
+      const uint32_t lo = adv ? rec.y : rec.x, hi = adv ? rec.z : rec.y;
+      int32_t value = (int32_t)rec.w + (adv ? 1 : 0);
+      uint32_t freq = hi - lo, d = (xlo & 0xFFFFu) - lo;
+      if (__builtin_expect(__any((xlo & 0xFFFFu) >= rec.z), 0)) {  // uniform and rare
+        if ((xlo & 0xFFFFu) >= rec.z) {
+          // this lane's symbol is finished HERE (walk, state update, bypass nibbles), and the common update below is handed
+          // an identity - frequency 2^16 at cdf 0 of the state as it then is - so that the fast path carries one test only
+          const uint32_t cf = xlo & 0xFFFFu;
+          int sidx = (int)rec.w - off;
+          if (sidx > len - 2) sidx = len - 2;  // (malformed tables only)
+          uint32_t slo = s_cdf[sidx], shi = s_cdf[sidx + 1];
+          while (sidx < len - 2 && shi <= cf) {
+            ++sidx;
+            slo = shi;
+            shi = s_cdf[sidx + 1];
+          }
+          value = sidx + off;
+          uint64_t x = ((uint64_t)xhi << 32) | xlo;
+          auto pull = [&]() {  // (reads past the end show in the read counter: checked after the last symbol)
+            if (x < RANS_L) {
+              x = (x << 32) | src.ring[(src.rd & (RING - 1)) * 64];
+              ++src.rd;
+            }
+          };
+          x = (uint64_t)(shi - slo) * (x >> 16) + cf - slo;
+          pull();
+          if (sidx == max_value) {  // the escape symbol: the value follows in bypass nibbles
+            auto bits4 = [&]() -> uint32_t {
+              const uint32_t v4 = (uint32_t)(x & 15u);
+              x >>= 4;
+              pull();
+              return v4;
+            };
+            uint32_t val = bits4();
+            int nbyp = (int)val;
+            while (val == 15u && nbyp < 64) { val = bits4(); nbyp += (int)val; }
+            uint32_t raw = 0;
+            for (int j = 0; j < nbyp; ++j) {
+              const uint32_t nib = bits4();
+              if (j < 8) raw |= nib << (j * 4);
+            }
+            int32_t v = (int32_t)(raw >> 1);
+            v = (raw & 1u) ? -v - 1 : v + max_value;
+            value = v + off;
+          }
+          freq = 65536u;
+          d = (uint32_t)x & 0xFFFFu;
+          Xlo = (uint32_t)(x >> 16);
+          Xhi = (uint32_t)(x >> 48);
+        }
+        src.refill_if_low();  // the escape path may have drained several words
+      }
+      // x' = freq * (x >> 16) + d: a 64-bit multiply-add for the low 32 bits of x >> 16, a full-rate 24-bit one for the 15 above
+      const uint64_t p = (uint64_t)Xlo * freq + (uint64_t)d;
+      const uint32_t plo = (uint32_t)p, nhi = __umul24(Xhi, freq) + (uint32_t)(p >> 32);
+      const bool need = (((uint64_t)nhi << 32) | plo) < rans_l;  // (an opaque 2^31: as a literal the compare becomes mask + compare-with-zero)
+      xhi = need ? plo : nhi;
+      xlo = need ? w_next : plo;
+      src.rd += need ? 1 : 0;
+      return value;
+    };
+
+    const size_t cbase = (size_t)c * plane;
+    if (SM) {  // plane % 4 == 0, 16-byte aligned rows (the launcher checks)
+      i32x4_t *dst = reinterpret_cast<i32x4_t *>(sp + cbase);
+      for (int p0 = 0; p0 < plane; p0 += SYM_BUF) {
+        src.refill_if_low();
+        const int nq = (plane - p0 < SYM_BUF ? plane - p0 : SYM_BUF) >> 2;
+        for (int q = 0; q < nq; ++q) {
+          i32x4_t v;
+          v.x = decode_one();
+          v.y = decode_one();
+          v.z = decode_one();
+          v.w = decode_one();
+          *dst++ = v;
+        }
+      }
+    } else {
+      static_assert(RING_LOW >= SYM_BUF, "a block may consume SYM_BUF words before the next ring check");
+      for (int p0 = 0; p0 < plane; p0 += SYM_BUF) {
+        src.refill_if_low();
+        const int nb = plane - p0 < SYM_BUF ? plane - p0 : SYM_BUF;
+        for (int k = 0; k < nb; ++k) s_out[k * 64 + lane] = decode_one();
+        for (int k = 0; k < nb; ++k) sp[(size_t)(cbase + p0 + k) * ssi] = s_out[k * 64 + lane];
+      }
+    }
+#ifdef LICOS_STAMPS
+    { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_loop += now_ - st_prev; st_prev = now_; }
+#endif
+  }
+#ifdef LICOS_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_dec_stamps[0], st_tab);
+    atomicAdd(&g_dec_stamps[1], st_loop);
+    atomicAdd(&g_dec_stamps[2], 1ull);
+  }
+#endif
+  if (live && src.rd > src.nw) atomicOr(status, 1);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Per-element-indexed fast path (GaussianConditional: the CDF row of every symbol is data).  The 64 rows have
@@ -761,6 +976,17 @@ static int coder_waves(int B) {
 
 extern "C" {
 
+#ifdef LICOS_STAMPS
+int licos_debug_dec_stamps(unsigned long long *out, int reset) {
+  if (out) LICOS_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 4));
+  if (reset) {
+    unsigned long long z[4] = {};
+    LICOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, sizeof(z)));
+  }
+  return LICOS_OK;
+}
+#endif
+
 int licos_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, long ssb, long ssi, int n, int plane,
                             const int32_t *cdf, int cdf_stride, const int32_t *cdf_len, const int32_t *offset,
                             const void *enc_table, uint32_t *words, int cap_words, int32_t *nwords, int32_t *status,
@@ -810,6 +1036,27 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   if (dec_lds > 156 * 1024) {  // very long tables: one wave per workgroup
     cw = 1;
     dec_lds = (size_t)(RING + SYM_BUF) * 64 * 4 + ((size_t)8 << LUT_BITS) + (size_t)cdf_stride * 4;
+  }
+  static const bool dec4 = [] { const char *e = getenv("LICOS_RANS_DEC4"); return !e || atoi(e) != 0; }();  // (A/B: 0 = the round-4 kernel)
+  if (dec4 && !indexes && n % plane == 0 && cdf_stride <= 65535) {
+    int w4 = coder_waves(B);
+    auto lds4 = [&](int w) { return (size_t)DEC_LUT_BYTES + (size_t)w * (RING + SYM_BUF) * 256 + (size_t)cdf_stride * 4; };
+    while (w4 > 1 && lds4(w4) > 156 * 1024) w4 /= 2;
+    if (lds4(w4) <= 156 * 1024) {
+      const bool sm = ssi == 1 && plane % 4 == 0 && ssb % 4 == 0 && ((uintptr_t)symbols & 15) == 0;
+      auto launch4 = [&](auto kern) -> int {
+        LICOS_ENSURE_LDS(kern, lds4(w4));
+        hipLaunchKernelGGL(kern, dim3(cdiv(B, 64 * w4)), dim3(64 * w4), lds4(w4), as_stream(stream), in, byte_off, ssb, ssi, n / plane, plane,
+                           cdf, cdf_stride, cdf_len, offset, symbols, status, B);
+        LICOS_LAUNCH_CHECK();
+        return LICOS_OK;
+      };
+      switch (w4) {
+        case 1: return sm ? launch4(rans_decode_plane4_kernel<1, true>) : launch4(rans_decode_plane4_kernel<1, false>);
+        case 2: return sm ? launch4(rans_decode_plane4_kernel<2, true>) : launch4(rans_decode_plane4_kernel<2, false>);
+        default: return sm ? launch4(rans_decode_plane4_kernel<4, true>) : launch4(rans_decode_plane4_kernel<4, false>);
+      }
+    }
   }
   if (!indexes && n % plane == 0 && dec_lds <= 156 * 1024 && cdf_stride <= 65535) {
     LICOS_ENSURE_LDS(rans_decode_plane_kernel, dec_lds);

@@ -261,8 +261,31 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(co
   const unsigned voff = (unsigned)b * 16u;
   const uint64_t row_bytes = (uint64_t)B * 16u;
   static_assert(ENC_BATCH == 8 && ENC_AHEAD == 4, "eight loads per request, vmcnt(48) = three batches of 8 loads + 8 stores");
-  u32x4 ring[ENC_AHEAD][ENC_BATCH];
-  auto request = [&](u32x4 (&slot)[ENC_BATCH], long t) {
+  // The ring lives in NAMED registers, v[128:255] (slot j, record k: v[128 + 32 j + 4 k ...]), that no C++ value ever
+  // occupies: a request only clobbers them, and the statement that waits is the one that DEFINES the slot's values
+  // (physical-register output constraints).  Passed through "+v" operands of the wait - the first form of this kernel -
+  // the allocator may give the operand another register and copy the ring's register into it IN FRONT of the wait: a copy
+  // of data still in flight (csrc/rans.hip, rans_encode_plane_kernel, where it was caught).  tests/test_host.py checks in
+  // the shipped library's disassembly that the compiler's own values stay below v128 in this kernel.
+#define LICOS_REC_RING_CLOBBER_10(B0)                                                                                                      \
+  "v" #B0 "0", "v" #B0 "1", "v" #B0 "2", "v" #B0 "3", "v" #B0 "4", "v" #B0 "5", "v" #B0 "6", "v" #B0 "7", "v" #B0 "8", "v" #B0 "9"
+  // (v128 .. v255 by decades: 12x = v120..v129 would name v120-v127 too, so the list starts at 128 explicitly)
+#define LICOS_REC_RING_CLOBBER                                                                                                             \
+  "v128", "v129", LICOS_REC_RING_CLOBBER_10(13), LICOS_REC_RING_CLOBBER_10(14), LICOS_REC_RING_CLOBBER_10(15), LICOS_REC_RING_CLOBBER_10(16), \
+      LICOS_REC_RING_CLOBBER_10(17), LICOS_REC_RING_CLOBBER_10(18), LICOS_REC_RING_CLOBBER_10(19), LICOS_REC_RING_CLOBBER_10(20),            \
+      LICOS_REC_RING_CLOBBER_10(21), LICOS_REC_RING_CLOBBER_10(22), LICOS_REC_RING_CLOBBER_10(23), LICOS_REC_RING_CLOBBER_10(24), "v250",    \
+      "v251", "v252", "v253", "v254", "v255"
+#define LICOS_REC_LD(S, K, OP) "global_load_dwordx4 v[" #S "+4*" #K ":" #S "+4*" #K "+3], %0, %" #OP "\n\t"
+#define LICOS_REC_RING_REQUEST(S)                                                                                                          \
+  asm volatile(LICOS_REC_LD(S, 0, 1) LICOS_REC_LD(S, 1, 2) LICOS_REC_LD(S, 2, 3) LICOS_REC_LD(S, 3, 4) LICOS_REC_LD(S, 4, 5)                 \
+                   LICOS_REC_LD(S, 5, 6) LICOS_REC_LD(S, 6, 7) LICOS_REC_LD(S, 7, 8)                                                         \
+               :: "v"(voff), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]), "s"(base[4]), "s"(base[5]), "s"(base[6]), "s"(base[7])  \
+               : "memory", LICOS_REC_RING_CLOBBER)
+#define LICOS_REC_RING_LANDED(WAIT, S0, S1, S2, S3, S4, S5, S6, S7)                                                                        \
+  asm volatile(WAIT : "={v[" S0 "]}"(cur[0]), "={v[" S1 "]}"(cur[1]), "={v[" S2 "]}"(cur[2]), "={v[" S3 "]}"(cur[3]), "={v[" S4 "]}"(cur[4]), \
+               "={v[" S5 "]}"(cur[5]), "={v[" S6 "]}"(cur[6]), "={v[" S7 "]}"(cur[7])::"memory")
+  auto request = [&](auto jc, long t) {
+    constexpr int j = decltype(jc)::value;
     // records n - 1 - 8 t - k, k = 0 .. 7: scalar row bases (wave-uniform), one 32-bit lane offset
     long i0 = n - 1 - t * ENC_BATCH;
     uint64_t base[ENC_BATCH];
@@ -271,49 +294,20 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(co
       const long i = i0 - k < 0 ? 0 : i0 - k;
       base[k] = reinterpret_cast<uint64_t>(rec) + (uint64_t)i * row_bytes;
     }
-#ifdef LICOS_GC_DEBUG  // (diagnostic builds: every address against the buffer before it is used)
-    {
-      const uint64_t lo = reinterpret_cast<uint64_t>(rec), hi = lo + (uint64_t)n * row_bytes;
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < ENC_BATCH; ++k) bad = bad || base[k] + voff < lo || base[k] + voff + 16 > hi;
-      if (__any(bad)) {
-        if (bad) {
-          atomicOr(status, 2);
-          atomicMax(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)t);
-          atomicMax(reinterpret_cast<unsigned long long *>(status + 4), base[0] - lo);
-        }
-#pragma unroll
-        for (int k = 0; k < ENC_BATCH; ++k) base[k] = lo;
-      }
-    }
-#endif
-#ifdef LICOS_GC_ENC_VADDR  // (A/B: 64-bit vector addresses instead of scalar base + lane offset)
-    const unsigned char *a8[ENC_BATCH];
-#pragma unroll
-    for (int k = 0; k < ENC_BATCH; ++k) a8[k] = reinterpret_cast<const unsigned char *>(base[k]) + voff;
-    asm volatile(
-        "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %9, off\n\tglobal_load_dwordx4 %2, %10, off\n\tglobal_load_dwordx4 %3, %11, off\n\t"
-        "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %13, off\n\tglobal_load_dwordx4 %6, %14, off\n\tglobal_load_dwordx4 %7, %15, off"
-        : "=&v"(slot[0]), "=&v"(slot[1]), "=&v"(slot[2]), "=&v"(slot[3]), "=&v"(slot[4]), "=&v"(slot[5]), "=&v"(slot[6]), "=&v"(slot[7])
-        : "v"(a8[0]), "v"(a8[1]), "v"(a8[2]), "v"(a8[3]), "v"(a8[4]), "v"(a8[5]), "v"(a8[6]), "v"(a8[7])
-        : "memory");
-#else
-    asm volatile(
-        "global_load_dwordx4 %0, %8, %9\n\tglobal_load_dwordx4 %1, %8, %10\n\tglobal_load_dwordx4 %2, %8, %11\n\tglobal_load_dwordx4 %3, %8, %12\n\t"
-        "global_load_dwordx4 %4, %8, %13\n\tglobal_load_dwordx4 %5, %8, %14\n\tglobal_load_dwordx4 %6, %8, %15\n\tglobal_load_dwordx4 %7, %8, %16"
-        : "=&v"(slot[0]), "=&v"(slot[1]), "=&v"(slot[2]), "=&v"(slot[3]), "=&v"(slot[4]), "=&v"(slot[5]), "=&v"(slot[6]), "=&v"(slot[7])
-        : "v"(voff), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]), "s"(base[4]), "s"(base[5]), "s"(base[6]), "s"(base[7])
-        : "memory");
-#endif
+    if constexpr (j == 0) LICOS_REC_RING_REQUEST(128);
+    if constexpr (j == 1) LICOS_REC_RING_REQUEST(160);
+    if constexpr (j == 2) LICOS_REC_RING_REQUEST(192);
+    if constexpr (j == 3) LICOS_REC_RING_REQUEST(224);
   };
-  auto landed48 = [&](u32x4 (&slot)[ENC_BATCH]) {
-    asm volatile("s_waitcnt vmcnt(48)"
-                 : "+v"(slot[0]), "+v"(slot[1]), "+v"(slot[2]), "+v"(slot[3]), "+v"(slot[4]), "+v"(slot[5]), "+v"(slot[6]), "+v"(slot[7])::"memory");
-  };
-  auto landed0 = [&](u32x4 (&slot)[ENC_BATCH]) {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(slot[0]), "+v"(slot[1]), "+v"(slot[2]), "+v"(slot[3]), "+v"(slot[4]), "+v"(slot[5]), "+v"(slot[6]), "+v"(slot[7])::"memory");
+  auto landed = [&](auto jc, auto counted, u32x4 (&cur)[ENC_BATCH]) {
+    constexpr int j = decltype(jc)::value;
+    constexpr bool COUNTED = decltype(counted)::value;
+#define LICOS_REC_LANDED_SLOT(WAIT)                                                                                                      \
+    if constexpr (j == 0) LICOS_REC_RING_LANDED(WAIT, "128:131", "132:135", "136:139", "140:143", "144:147", "148:151", "152:155", "156:159"); \
+    if constexpr (j == 1) LICOS_REC_RING_LANDED(WAIT, "160:163", "164:167", "168:171", "172:175", "176:179", "180:183", "184:187", "188:191"); \
+    if constexpr (j == 2) LICOS_REC_RING_LANDED(WAIT, "192:195", "196:199", "200:203", "204:207", "208:211", "212:215", "216:219", "220:223"); \
+    if constexpr (j == 3) LICOS_REC_RING_LANDED(WAIT, "224:227", "228:231", "232:235", "236:239", "240:243", "244:247", "248:251", "252:255");
+    if constexpr (COUNTED) { LICOS_REC_LANDED_SLOT("s_waitcnt vmcnt(48)") } else { LICOS_REC_LANDED_SLOT("s_waitcnt vmcnt(0)") }
   };
   WordSink sink{words, ((uint32_t)cap_words * (uint32_t)B + (uint32_t)b) * 4u, (uint32_t)B * 4u};
 #ifdef LICOS_GC_DEBUG
@@ -364,31 +358,28 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(co
   };
   // prologue: four batches requested, landed before the loop (the first pass has fewer operations behind its requests
   // than the loop's counted wait assumes)
-#pragma unroll
-  for (int j = 0; j < ENC_AHEAD; ++j) request(ring[j], j);
-#pragma unroll
-  for (int j = 0; j < ENC_AHEAD; ++j) landed0(ring[j]);
+  static_for<ENC_AHEAD>([&](auto jc) { request(jc, (long)decltype(jc)::value); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // whole groups of four FULL batches: counted waits; the ragged end (the last group, whose last batch may be short and
   // issue fewer stores than the count assumes) waits for everything
   const long full_groups = (n / ENC_BATCH) / ENC_AHEAD;
   long t = 0;
   for (long g = 0; g < full_groups; ++g) {
-#pragma unroll
-    for (int j = 0; j < ENC_AHEAD; ++j, ++t) {
-      landed48(ring[j]);
-      code_batch(ring[j], t);
-      request(ring[j], t + ENC_AHEAD);
-    }
+    static_for<ENC_AHEAD>([&](auto jc) {
+      u32x4 cur[ENC_BATCH];
+      landed(jc, std::true_type{}, cur);
+      code_batch(cur, t);
+      request(jc, t + ENC_AHEAD);
+      ++t;
+    });
   }
-  // The requests that ran past the front of the stream are still in flight: they must land before the compiler may give
-  // the ring's registers to anything else - an address of the epilogue below, say, which a late load would overwrite (found
-  // as a memory fault at >= 1024 streams, where the loads are slow enough to land behind the loop).
-#pragma unroll
-  for (int j = 0; j < ENC_AHEAD; ++j) landed0(ring[j]);
-#pragma unroll
-  for (int j = 0; j < ENC_AHEAD; ++j, ++t) {
-    if (t < nbat) code_batch(ring[j], t);
-  }
+  // the requests that ran past the front of the stream are still in flight: every slot lands before its tail batch is coded
+  static_for<ENC_AHEAD>([&](auto jc) {
+    u32x4 cur[ENC_BATCH];
+    landed(jc, std::false_type{}, cur);
+    if (t < nbat) code_batch(cur, t);
+    ++t;
+  });
   if (live) {
     sink.put((uint32_t)(x >> 32));
     sink.put((uint32_t)x);

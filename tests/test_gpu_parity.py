@@ -450,6 +450,51 @@ def test_rans_plane_path_with_escapes(batch):
     assert torch.equal(out.cpu(), om.eb_decompress(ref, (4, 6), sd))
 
 
+@pytest.mark.parametrize("batch,hw", [(1, (4, 6)), (3, (3, 5)), (64, (16, 16)), (130, (4, 6)), (130, (16, 16)), (200, (2, 2))])
+def test_rans_plane_decoder_both_symbol_layouts(batch, hw):
+    """The round-5 plane decoder (csrc/rans.hip rans_decode_plane4_kernel) against the oracle's symbols, [position][stream] and
+    [stream][position] (16-byte stores from registers when the plane is a multiple of 4, the strided form otherwise), with
+    out-of-range values on both sides (the escape path rides on the rare-bucket test), ragged wave fill, one and two waves
+    per workgroup (batch <= 64 / above; four: LICOS_CODER_WAVES=4 runs of tools/eb_coder_bench.py)."""
+    sd = om.perturb_state(om.make_factorized_state(3, 1), seed=5)
+    net = _load(3, sd)
+    eb = net.entropy_bottleneck
+    om.eb_update(sd)
+    h, w = hw
+    g = torch.Generator().manual_seed(batch + h)
+    y = 6 * torch.randn(batch, 192, h, w, generator=g)
+    y[0, 7, h - 1, w - 1] = 4321.5
+    y[-1, 100, 0, 0] = -70000.25
+    y[batch // 2, 191, 0, 1] = 3.0e6
+    ref = om.eb_compress(y, sd)
+    want = torch.round(y - torch.from_numpy(np.asarray(om.eb_medians(sd), dtype=np.float32)).view(1, -1, 1, 1)).to(torch.int32)
+    cdf, cdf_len, offset, _ = eb.coder_tables()
+    data, byte_off = eb.pack_strings(ref, DEV)
+    n, plane = 192 * h * w, h * w
+    pm = torch.empty((n, batch), dtype=torch.int32, device=DEV)
+    st = ops.rans_decode_batch(data, byte_off, 1, batch, n, plane, cdf, cdf_len, offset, pm, batch)
+    assert int(st.item()) == 0
+    assert torch.equal(pm.t().cpu(), want.reshape(batch, n))
+    buf = torch.full((batch, n + 4), -7, dtype=torch.int32, device=DEV)  # (a row stride that is not the stream length)
+    sm = buf[:, :n]
+    st = ops.rans_decode_batch(data, byte_off, n + 4, 1, n, plane, cdf, cdf_len, offset, buf, batch)
+    assert int(st.item()) == 0
+    assert torch.equal(sm.cpu(), want.reshape(batch, n)) and bool((buf[:, n:] == -7).all())
+    # ... and dequantised straight from the stream-major symbols into the transforms' blk16 layout
+    if plane % 64 == 0:
+        smc = sm.contiguous()
+        blk = torch.empty((batch, 12, h, w, 16), dtype=torch.float16, device=DEV)
+        ops.eb_dequantize(smc, n, 1, eb.medians_vec(), batch, 192, h, w, want_nchw=False, blk16=blk)
+        ref_hat = ops.eb_dequantize(pm, 1, batch, eb.medians_vec(), batch, 192, h, w)
+        got = blk.permute(0, 1, 4, 2, 3).reshape(batch, 192, h, w).float()
+        assert torch.equal(got, ref_hat.to(torch.float16).float())
+    # a truncated string is reported
+    short = [r[:8] for r in ref]
+    data2, off2 = eb.pack_strings(short, DEV)
+    st = ops.rans_decode_batch(data2, off2, n + 4, 1, n, plane, cdf, cdf_len, offset, buf, batch)
+    assert int(st.item()) != 0 or all(len(r) == 8 for r in ref)
+
+
 def test_flat_state_average_single_gpu():
     """World size 1 on the GPU: the HIP scale kernels around the (absent) collective are an identity,
     parameters live in the bucket, and the fp16 path picks the re-homed weights up."""

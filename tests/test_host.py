@@ -513,3 +513,84 @@ def test_hyper_host_share_policy(monkeypatch):
     monkeypatch.setattr(codec.config, "host_split", True)
     monkeypatch.setattr(ops, "HOST_CODER", "0")
     assert codec.hyper_host_share(4096, "dec") == 0
+
+
+def test_prefetch_ring_registers_belong_to_the_ring_alone(tmp_path):
+    """The stream-major plane encoder (csrc/rans.hip) and the record encoder (csrc/rans_gc.hip) keep symbols on their way from
+    memory in NAMED registers (v200-v231 / v128-v255, four slots) and define the values only in the statement that waits for
+    them: the first form passed them through ordinary asm operands, and the register allocator copied them in front of the
+    wait (intermittently stale symbols).  Checked in the shipped library's disassembly, in address order: from a slot's
+    request to that slot's own counted wait nothing touches its registers, nothing touches a slot between the prologue and
+    its first wait in the loop (cyclically: behind its request at the loop's end), and nothing else is ever loaded there."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    so = os.path.join(ROOT, "licos_amd", "liblicos_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(so)):
+        pytest.skip("needs llvm-objdump and the built library")
+    shutil.copy(so, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    # kernel -> (first ring register, registers per slot, the loop's counted wait)
+    wanted = {"rans_encode_plane_kernel": (200, 8, 30), "rans_encode_records_regs_kernel": (128, 32, 48)}
+    checked = {}
+
+    def regs_of(text):
+        out = {int(r) for r in re.findall(r"\bv(\d+)\b", text)}
+        for lo_, hi_ in re.findall(r"v\[(\d+):(\d+)\]", text):
+            out.update(range(int(lo_), int(hi_) + 1))
+        return out
+
+    def check(kernel, body):
+        first, per_slot, counted = wanted[next(k for k in wanted if k in kernel)]
+        slot_of = lambda r: (r - first) // per_slot
+        in_flight = [False] * 4
+        before_first_wait = None  # set at the prologue's vmcnt(0)
+        n_counted = n_loads = 0
+        for ins in body:
+            parts = ins.split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ins)
+            if m:
+                if int(m.group(1)) == 0:
+                    in_flight = [False] * 4
+                    if before_first_wait is None:
+                        before_first_wait = [True] * 4
+                elif int(m.group(1)) == counted:
+                    j = n_counted % 4
+                    n_counted += 1
+                    in_flight[j] = False
+                    if before_first_wait is not None:
+                        before_first_wait[j] = False
+                continue
+            ring = {r for r in regs_of(args) if r >= first}
+            if not ring:
+                continue
+            slots = {slot_of(r) for r in ring}
+            if op == "global_load_dwordx4" and regs_of(args.split(",")[0]) == ring:  # a request
+                assert len(slots) == 1
+                in_flight[slots.pop()] = True
+                n_loads += 1
+                continue
+            assert not op.startswith(("global_load", "buffer_load", "flat_load", "ds_read")) or not (regs_of(args.split(",")[0]) & ring), \
+                "%s: a load of the compiler's own into the ring: %s" % (kernel, ins)
+            for j in slots:
+                assert not in_flight[j], "%s: slot %d touched between its request and its wait: %s" % (kernel, j, ins)
+                assert before_first_wait is None or not before_first_wait[j], \
+                    "%s: slot %d touched in front of its first wait in the loop: %s" % (kernel, j, ins)
+        assert n_loads >= 16 and n_counted >= 4, (kernel, n_loads, n_counted)
+        checked[kernel] = (n_loads, n_counted)
+
+    for obj in sorted(tmp_path.glob("*gfx950")):
+        dis = subprocess.run([objdump, "-d", str(obj)], capture_output=True, text=True, check=True).stdout
+        name, body = None, []
+        for line in dis.splitlines() + ["0 <end>:"]:
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                if name:
+                    check(name, body)
+                name = m.group(1) if any(k in m.group(1) for k in wanted) else None
+                body = []
+            elif name and line.strip():
+                body.append(line.split("//")[0].strip())
+    assert any("rans_encode_plane_kernel" in k for k in checked) and any("rans_encode_records_regs_kernel" in k for k in checked), checked

@@ -1,0 +1,276 @@
+// Last synthesis stage for 5..16 output channels (the 13 merged Sentinel-2 bands), row-walking form on v_mfma_f32_16x16x32_f16:
+// the input is read ONCE, straight into MFMA B fragments - no patch staged through LDS, no halo columns, no second pass.
+//
+// ConvTranspose2d(128 -> C, 5x5, stride 2, padding 2, output_padding 1), the same split as csrc/mfma_rows.hip:
+//     Z[(py, kx, c)][y][x'] = sum_{dy in -1..1} sum_cin W[cin][c][py + 2 - 2dy][kx] * X[cin][y + dy][x']
+//     out[(py, px, c)][y][x] = bias[c] + sum_{kx = px mod 2} Z[(py, kx, c)][y][x + (px + 2 - kx) / 2]
+// With 13 channels the rows (py, kx, c) are TEN 16-row tiles (py, kx) x (c < 16) - the 16 x 16 x 32 shape, 81 % of its rows
+// useful against 68 % of five 32-row tiles - and K = 32 is a PAIR of 16-channel chunks (lane k-group g = lane / 16: chunk
+// g / 2 of the pair, half g % 2).  dy = -1 only meets py = 0 (kernel row 4): 5 + 10 + 10 tiles per chunk pair, 100 A
+// fragments (100 KB, resident in LDS) and 200 MFMAs per 32 input pixels - what deconv5x5s2_few16_kernel
+// (csrc/mfma_deconv.hip) issues too, but its B operands came through an LDS patch with a halo (1.2 x the input, staged with
+// vmcnt(0) + two barriers per chunk pair: 0.46 - 0.47 of the HBM roof in the config-5 bench).  Here a wave owns 32 columns
+// (two 16-pixel B tiles) and walks DOWN its strip with three input rows in registers (each row is loaded once and used by
+// three consecutive steps; the next row is requested as soon as row y - 1 has been multiplied), eight waves side by side
+// cover 256 columns - a whole row of the 256-wide maps of config 5.
+//
+// The x shift: a D tile holds channel 4 g + i of pixel lane % 16, so the neighbour pixel is the neighbour LANE - two DPP
+// moves per value (row_shl / row_shr within the 16 lanes of a k-group, the lane at the tile's end filled from the other
+// tile's rotated register), and only the two columns at a wave's edges go through LDS (96 floats per wave and row, one
+// barrier per row, slots alternate with the row's parity).  Then bias, clamp, one 8-byte store per channel and output row
+// (px = 0, 1 of a lane are adjacent output pixels).  Sums are fp32 in a fixed order (dy, chunk pair; then kx = 2|3, 0|1, 4):
+// bit-reproducible, and a tile's result does not depend on the batch or on the row-block size.
+#include "mfma_common.hpp"
+
+#ifndef LICOS_ROWS16_RH
+#define LICOS_ROWS16_RH 32
+#endif
+
+namespace licos {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned v2u32_t __attribute__((ext_vector_type(2)));
+
+struct Rows16Args {
+  const half8 *x;     // blk16 input [B][8][H][W][16] (or its x-split form)
+  const half8 *wp;    // [100][64 lanes] A fragments (licos_pack_deconv_w_rows_f16 for 5..16 output channels)
+  const float *bias;  // [C]
+  float *y;           // NCHW fp32 [B][C][2H][2W]
+  int B, H, W, C, tiles_x, tiles_y, rows_per_wg, clamp01, in_xsplit;
+};
+
+constexpr int R16_WAVES = 8, R16_COLS = 32 * R16_WAVES, R16_NFRAG = 100, R16_CC = 8, R16_PAIRS = R16_CC / 2;
+constexpr int R16_EDGE_L = 2 * 16, R16_EDGE_R = 16;                               // floats a wave hands left (kx 0, 1) / right (kx 4), per parity
+constexpr int R16_EDGE_SLOT = (R16_WAVES + 2) * (R16_EDGE_L + R16_EDGE_R);        // (a never-written zero entry on either side)
+constexpr int R16_LDS = R16_NFRAG * 64 * 16 + 2 * R16_EDGE_SLOT * 4 + 16 * 4;
+
+// fragment `it` of a row's 100: d = dy + 1 outermost, then the chunk pair, then the tile (py, kx) - d = 0 has the py = 0 tiles only
+struct R16Frag { int d, pair, py, kx; };
+__host__ __device__ constexpr R16Frag r16_frag(int it) {
+  const int d = it < 20 ? 0 : it < 60 ? 1 : 2, rem = it - (d == 0 ? 0 : d == 1 ? 20 : 60), cnt = d == 0 ? 5 : 10;
+  const int pair = rem / cnt, tl = rem % cnt;
+  return R16Frag{d, pair, d == 0 ? 0 : tl / 5, tl % 5};
+}
+
+// the n-th fragment of output-row parity py: (d, pair, kx) in that order, d = 0 only for py = 0
+__host__ __device__ constexpr int r16_pass_frag(int py, int n) {
+  if (py == 0) {
+    if (n < 20) return n;                                        // d = 0: pair * 5 + kx
+    const int m = n - 20, d = 1 + m / 20, r = m % 20;            // d = 1, 2: 20 each
+    return (d == 1 ? 20 : 60) + (r / 5) * 10 + r % 5;
+  }
+  const int d = 1 + n / 20, r = n % 20;
+  return (d == 1 ? 20 : 60) + (r / 5) * 10 + 5 + r % 5;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_keep(float old, float src) {  // lanes whose source falls outside the row keep `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR15 = 0x12F;
+
+template <int RING>
+__global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows16Args a) {
+  static_assert(RING == 3, "rows y - 1, y, y + 1; the slot of y - 1 takes row y + 2 once it has been multiplied");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  half8 *s_w = reinterpret_cast<half8 *>(smem);                                    // [100][64]
+  float *s_edge = reinterpret_cast<float *>(smem + (size_t)R16_NFRAG * 64 * 16);   // [2 parities][waves + 2][L 32 | R 16]
+  float *s_bias = s_edge + 2 * R16_EDGE_SLOT;                                      // [16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px_l = lane & 15, g = lane >> 4;
+  int b, tile;
+  xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int y0 = tyi * a.rows_per_wg, y1 = min(y0 + a.rows_per_wg, a.H);
+  // one strip covers maps up to 256 wide; wider maps: strips of 254 live columns with one shared column on either side
+  const int xorg = a.tiles_x == 1 ? 0 : (R16_COLS - 2) * txi - 1;
+
+  for (int e = tid; e < R16_NFRAG * 64; e += 64 * R16_WAVES) s_w[e] = a.wp[e];
+  for (int e = tid; e < 2 * R16_EDGE_SLOT; e += 64 * R16_WAVES) s_edge[e] = 0.f;
+
+  // The image as a raw buffer: a lane outside the map (and every lane of a row outside it) asks for an offset past
+  // num_records and gets zeros - no branch, no select, so a row's loads can stay in flight across steps.
+  const unsigned plane_bytes = (unsigned)a.H * a.W * 32u;  // one 16-channel chunk of the image
+  const half8 *xb = a.x + (size_t)b * R16_CC * (plane_bytes >> 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(xb), 0, (int)(R16_CC * plane_bytes), 0x00020000);
+  const unsigned OOB = 0x80000000u;  // (the launcher keeps an image below 2^31 bytes)
+  // ... and so is the output: a lane without a live pixel, or a channel slot past C, stores past num_records - nowhere.
+  // One 32-bit offset per (channel, tile) and lane for the whole walk; the output row is a scalar offset.
+  const int Ho = 2 * a.H, Wo = 2 * a.W;
+  float *yb = a.y + (size_t)b * a.C * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((unsigned)a.C * Ho * Wo * 4u), 0x00020000);
+  unsigned lane_off[2], out_off[2];
+  const unsigned chan_bytes = (unsigned)Ho * Wo * 4u;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = 32 * wave + 16 * t + px_l, x = xorg + col;
+    const bool x_in = x >= 0 && x < a.W;
+    const bool x_live = x_in && (a.tiles_x == 1 || (col >= 1 && col <= R16_COLS - 2));
+    const int pixoff = a.in_xsplit ? (x & 1) * (a.W >> 1) + (x >> 1) : x;
+    // (the lane's k-group picks chunk g / 2 of a pair and the half g % 2 of its 16 channels)
+    lane_off[t] = x_in ? (unsigned)pixoff * 32u + (unsigned)(g >> 1) * plane_bytes + (unsigned)(g & 1) * 16u : OOB;
+    out_off[t] = x_live ? (unsigned)(4 * g) * chan_bytes + 8u * x : OOB;  // channel 4 g; + i channels: a scalar offset per store
+  }
+  const unsigned row_bytes = (unsigned)a.W * 32u;
+  auto load_row = [&](half8 (&dst)[2][R16_PAIRS], int y) __attribute__((always_inline)) {
+    const unsigned yoff = (unsigned)y * row_bytes, oob = (unsigned)y < (unsigned)a.H ? 0u : OOB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < R16_PAIRS; ++p)
+        dst[t][p] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (yoff + lane_off[t]) | oob, 2 * p * plane_bytes, 0));
+  };
+
+  if (tid < 16) s_bias[tid] = tid < a.C ? a.bias[tid] : 0.f;
+  // this wave's edge values live in entry wave + 1 of a slot; the neighbours' are entries wave + 2 (right) and wave (left)
+  float *edge_mine = s_edge + (wave + 1) * (R16_EDGE_L + R16_EDGE_R) + 4 * g;
+
+  half8 row[RING][2][R16_PAIRS];
+#pragma unroll
+  for (int i = 0; i < RING; ++i) load_row(row[i], y0 - 1 + i);
+  __syncthreads();  // weights staged, edge slots zeroed
+
+  auto step = [&](auto jc, int y) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;  // (y - y0) mod RING: row y - 1 in slot j, y in j + 1, y + 1 in j + 2
+    // The two output-row parities one after the other (py = 0: 60 fragments, dy = -1 included; py = 1: 40): both sets of
+    // accumulators beside the three rows do not fit the register file.  Row y - 1 is done after py = 0's first 20 fragments.
+    static_for<2>([&](auto pyc) {
+      constexpr int py = decltype(pyc)::value;
+      constexpr int NF = py == 0 ? 60 : 40;
+      __builtin_amdgcn_sched_barrier(0);  // (and a parity's epilogue is not interleaved with the next multiplications)
+      f32x4 acc[5][2];
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[kx][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // each A fragment is multiplied into both pixel tiles; read from LDS two fragments ahead of its use
+      half8 a_cur = s_w[r16_pass_frag(py, 0) * 64 + lane], a_nxt = s_w[r16_pass_frag(py, 1) * 64 + lane];
+      static_for<NF>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr R16Frag f = r16_frag(r16_pass_frag(py, n));
+        half8 a_nn = a_nxt;
+        if (n + 2 < NF) a_nn = s_w[r16_pass_frag(py, n + 2 < NF ? n + 2 : 0) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[f.kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, row[(j + f.d) % RING][t][f.pair], acc[f.kx][t], 0, 0, 0);
+        a_cur = a_nxt;
+        a_nxt = a_nn;
+        // (a fence every four fragments: left alone, the scheduler hoists the fragment reads as far as the register file
+        // lets it - twenty in flight - and past it, into scratch)
+        if (n % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        // row y - 1 has been multiplied: its slot takes row y + RING - 1
+        // (pinned here: left alone, the scheduler sinks the requests below the last MFMA and shortens their flight)
+        if (py == 0 && n == 19) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_row(row[j], y + RING - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      // the two columns at this wave's edges, for the waves on either side (one slot per parity)
+      float *slot = edge_mine + py * R16_EDGE_SLOT;
+      if (px_l == 0) {
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) *reinterpret_cast<f32x4 *>(slot + kx * 16) = acc[kx][0];
+      }
+      if (px_l == 15) *reinterpret_cast<f32x4 *>(slot + R16_EDGE_L) = acc[4][1];
+      // (not __syncthreads(): its fence may drain vmcnt, and the next rows' loads must stay in flight across the barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const float *right = slot + (R16_EDGE_L + R16_EDGE_R), *left = slot - (R16_EDGE_L + R16_EDGE_R);
+      const f32x4 bias_c = *reinterpret_cast<const f32x4 *>(s_bias + 4 * g);
+      const f32x4 e0 = *reinterpret_cast<const f32x4 *>(right), e1 = *reinterpret_cast<const f32x4 *>(right + 16);
+      const f32x4 e4 = *reinterpret_cast<const f32x4 *>(left + R16_EDGE_L);
+      const unsigned row_off = (unsigned)(2 * y + py) * Wo * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // pixel x + 1's kx = 0, 1 and pixel x - 1's kx = 4, per tile: the neighbour lane, the tile's last lane from the other
+        // tile (rotated into place first) or from the neighbour wave
+        const float r0_t0 = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[0][1][i]), acc[0][0][i]);
+        const float r1_t0 = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[1][1][i]), acc[1][0][i]);
+        const float r0_t1 = dpp_keep<DPP_ROW_SHL1>(e0[i], acc[0][1][i]);
+        const float r1_t1 = dpp_keep<DPP_ROW_SHL1>(e1[i], acc[1][1][i]);
+        const float l4_t1 = dpp_keep<DPP_ROW_SHR1>(dpp_keep<DPP_ROW_ROR1>(0.f, acc[4][0][i]), acc[4][1][i]);
+        const float l4_t0 = dpp_keep<DPP_ROW_SHR1>(e4[i], acc[4][0][i]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float o0 = (acc[2][t][i] + (t ? r0_t1 : r0_t0)) + (t ? l4_t1 : l4_t0) + bias_c[i];
+          float o1 = (acc[3][t][i] + (t ? r1_t1 : r1_t0)) + bias_c[i];
+          if (a.clamp01) {
+            o0 = fminf(fmaxf(o0, 0.f), 1.f);
+            o1 = fminf(fmaxf(o1, 0.f), 1.f);
+          }
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          // (a channel slot past C - the last k-group's - stores past num_records as well: the scalar part of an address is
+          // not range-checked, the lane's is)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, f32x2{o0, o1}), orsrc, 4 * g + i < a.C ? out_off[t] : OOB,
+                                                row_off + i * chan_bytes, 0);
+        }
+      }
+    });
+  };
+  // whole turns of the ring without a condition inside (with one, the compiler has to assume at the loop head that the
+  // newest loads are the ones the first MFMA needs, and waits for vmcnt(0)); the last RING - 1 steps at most after it
+  int y = y0;
+  for (; y + RING <= y1; y += RING) static_for<RING>([&](auto jc) { step(jc, y + decltype(jc)::value); });
+  static_for<RING - 1>([&](auto jc) {
+    if (y + decltype(jc)::value < y1) step(jc, y + decltype(jc)::value);
+  });
+}
+
+// w: ConvTranspose2d weight [Cin][C][5][5] fp32 -> the 100 A fragments [it][lane][8]: row = lane & 15 = c, k = 8 (lane >> 4) + e:
+// chunk 2 pair + (lane >> 5), channel 8 ((lane >> 4) & 1) + e of it; value W[cin][c][py + 4 - 2 d][kx]
+__global__ void pack_deconv_w_rows16_kernel(const float *__restrict__ w, int Cin, int C, _Float16 *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R16_NFRAG * 512; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63, it = i >> 9;
+    const R16Frag f = r16_frag(it);
+    const int c = lane & 15, gg = lane >> 4;
+    const int cin = 16 * (2 * f.pair + (gg >> 1)) + 8 * (gg & 1) + e, ky = f.py + 4 - 2 * f.d;
+    float v = 0.f;
+    if (c < C && cin < Cin && ky >= 0 && ky <= 4) v = w[(((size_t)cin * C + c) * 5 + ky) * 5 + f.kx];
+    out[i] = (_Float16)v;
+  }
+}
+
+size_t rows16_packed_bytes(int Cin, int Cout) {
+  if ((Cin + 15) / 16 != R16_CC || Cout < 5 || Cout > 16) return 0;
+  return (size_t)R16_NFRAG * 64 * 16;
+}
+
+int rows16_pack(const float *w, int Cin, int Cout, void *packed, hipStream_t s) {
+  hipLaunchKernelGGL(pack_deconv_w_rows16_kernel, dim3(cdiv(R16_NFRAG * 512, 256)), dim3(256), 0, s, w, Cin, Cout, reinterpret_cast<_Float16 *>(packed));
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, float *y_nchw, int flags, int B, int Cin, int H, int W, int Cout,
+                  hipStream_t s) {
+  LICOS_REQUIRE((Cin + 15) / 16 == R16_CC && Cout >= 5 && Cout <= 16, "deconv5x5s2_rows_f16: 5..16 output channels need 113..128 input channels");
+  Rows16Args a{};
+  a.x = reinterpret_cast<const half8 *>(x_blk16);
+  a.wp = reinterpret_cast<const half8 *>(w_packed);
+  a.bias = bias;
+  a.y = y_nchw;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.C = Cout;
+  a.clamp01 = flags & 1;
+  a.in_xsplit = (flags >> 1) & 1;
+  LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_rows_f16: x-split input needs an even width");
+  LICOS_REQUIRE((long)Cout * 4 * H * W * 4 < (1L << 31), "deconv5x5s2_rows_f16: an image's output must stay below 2 GB (buffer offsets)");
+  a.tiles_x = W <= R16_COLS ? 1 : cdiv(W, R16_COLS - 2);
+  // row blocks: 32 rows when that still fills the chip (input read (32 + 2) / 32 times), 8 rows for small calls
+  a.rows_per_wg = (long)B * a.tiles_x * cdiv(H, LICOS_ROWS16_RH) >= 1024 ? LICOS_ROWS16_RH : 8;
+  a.tiles_y = cdiv(H, a.rows_per_wg);
+  auto kern = deconv5x5s2_rows16_kernel<3>;
+  LICOS_ENSURE_LDS(kern, R16_LDS);
+  const long blocks = (long)a.tiles_x * a.tiles_y * a.B;
+  LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_rows_f16: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), R16_LDS, s, a);
+  LICOS_LAUNCH_CHECK();
+  return LICOS_OK;
+}
+
+}  // namespace licos

@@ -202,6 +202,12 @@ static int launch_rows(const RowsArgs &a, hipStream_t s) {
 }
 
 
+// 5 .. 16 output channels: csrc/mfma_rows16.hip
+size_t rows16_packed_bytes(int Cin, int Cout);
+int rows16_pack(const float *w, int Cin, int Cout, void *packed, hipStream_t s);
+int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, float *y_nchw, int flags, int B, int Cin, int H, int W, int Cout,
+                  hipStream_t s);
+
 }  // namespace licos
 
 using namespace licos;
@@ -209,12 +215,14 @@ using namespace licos;
 extern "C" {
 
 size_t licos_packed_deconv_w_rows_bytes(int Cin, int Cout) {
-  if (Cin <= 0 || Cout <= 0 || Cout > 3) return 0;
+  if (Cin <= 0 || Cout <= 0) return 0;
+  if (Cout > 3) return rows16_packed_bytes(Cin, Cout);
   return (size_t)3 * ((Cin + 15) / 16) * 64 * 16;
 }
 
 int licos_pack_deconv_w_rows_f16(const float *w, int Cin, int Cout, void *packed, void *stream) {
-  LICOS_REQUIRE(w && packed && Cin > 0 && Cout > 0 && Cout <= 3, "pack_deconv_w_rows_f16: needs 1..3 output channels");
+  if (w && packed && Cout > 3 && rows16_packed_bytes(Cin, Cout)) return rows16_pack(w, Cin, Cout, packed, as_stream(stream));
+  LICOS_REQUIRE(w && packed && Cin > 0 && Cout > 0 && Cout <= 3, "pack_deconv_w_rows_f16: needs 1..3 output channels (5..16 from 113..128 input channels)");
   const long total = (long)3 * ((Cin + 15) / 16) * 64 * 8;
   hipLaunchKernelGGL(pack_deconv_w_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, Cin, Cout,
                      reinterpret_cast<_Float16 *>(packed), total);
@@ -225,8 +233,10 @@ int licos_pack_deconv_w_rows_f16(const float *w, int Cin, int Cout, void *packed
 int licos_deconv5x5s2_rows_f16(const void *x_blk16, const void *w_packed_rows, const float *bias, float *y_nchw, int clamp01, int B,
                                int Cin, int H, int W, int Cout, void *stream) {
   LICOS_REQUIRE(x_blk16 && w_packed_rows && bias && y_nchw, "deconv5x5s2_rows_f16: null buffer");
-  LICOS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 3, "deconv5x5s2_rows_f16: needs 1..3 output channels");
+  LICOS_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (Cout <= 3 || rows16_packed_bytes(Cin, Cout)),
+                "deconv5x5s2_rows_f16: needs 1..3 output channels, or 5..16 from 113..128 input channels");
   LICOS_REQUIRE((long)((Cin + 15) / 16) * H * W * 32 < (1L << 31), "deconv5x5s2_rows_f16: an image's input must stay below 2 GB (buffer offsets)");
+  if (Cout > 3) return rows16_launch(x_blk16, w_packed_rows, bias, y_nchw, clamp01, B, Cin, H, W, Cout, as_stream(stream));
   RowsArgs a{};
   a.x = reinterpret_cast<const half8 *>(x_blk16);
   a.wp = reinterpret_cast<const half8 *>(w_packed_rows);

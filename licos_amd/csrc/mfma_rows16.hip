@@ -22,8 +22,19 @@
 // bit-reproducible, and a tile's result does not depend on the batch or on the row-block size.
 #include "mfma_common.hpp"
 
+// A/B builds only (tools/ab_build.sh): rows per workgroup for large calls, cache-policy bits of the output stores (raw
+// buffer aux: 1 sc0, 2 nt, 16 sc1)
 #ifndef LICOS_ROWS16_RH
 #define LICOS_ROWS16_RH 32
+#endif
+#ifndef LICOS_ROWS16_AHEAD
+#define LICOS_ROWS16_AHEAD 4
+#endif
+#ifndef LICOS_ABL_R16
+#define LICOS_ABL_R16 0
+#endif
+#ifndef LICOS_ROWS16_STORE_AUX
+#define LICOS_ROWS16_STORE_AUX 2  // (nt: +2 % on the stage alone, profiles/r05_last16_probe.log)
 #endif
 
 namespace licos {
@@ -52,15 +63,13 @@ __host__ __device__ constexpr R16Frag r16_frag(int it) {
   return R16Frag{d, pair, d == 0 ? 0 : tl / 5, tl % 5};
 }
 
-// the n-th fragment of output-row parity py: (d, pair, kx) in that order, d = 0 only for py = 0
+// the n-th fragment of output-row parity py: d = 0 of every tile first (py = 0 only: 20 fragments, pair-major as packed), then
+// d = 1, 2 tile by tile - kx = 0, 1, 4 (24 fragments), whose values go to the neighbour pixels, and kx = 2, 3 (16) last
 __host__ __device__ constexpr int r16_pass_frag(int py, int n) {
-  if (py == 0) {
-    if (n < 20) return n;                                        // d = 0: pair * 5 + kx
-    const int m = n - 20, d = 1 + m / 20, r = m % 20;            // d = 1, 2: 20 each
-    return (d == 1 ? 20 : 60) + (r / 5) * 10 + r % 5;
-  }
-  const int d = 1 + n / 20, r = n % 20;
-  return (d == 1 ? 20 : 60) + (r / 5) * 10 + 5 + r % 5;
+  if (py == 0 && n < 20) return n;
+  const int m = py == 0 ? n - 20 : n;
+  const int kx = m < 24 ? (m / 8 == 2 ? 4 : m / 8) : 2 + (m - 24) / 8, r = m % 8, d = 1 + r / 4, pair = r % 4;
+  return (d == 1 ? 20 : 60) + pair * 10 + py * 5 + kx;
 }
 
 template <int CTRL>
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
   const int Ho = 2 * a.H, Wo = 2 * a.W;
   float *yb = a.y + (size_t)b * a.C * Ho * Wo;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((unsigned)a.C * Ho * Wo * 4u), 0x00020000);
-  unsigned lane_off[2], out_off[2];
+  unsigned lane_off[2], out_off[2][4];
   const unsigned chan_bytes = (unsigned)Ho * Wo * 4u;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -110,8 +119,12 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
     const int pixoff = a.in_xsplit ? (x & 1) * (a.W >> 1) + (x >> 1) : x;
     // (the lane's k-group picks chunk g / 2 of a pair and the half g % 2 of its 16 channels)
     lane_off[t] = x_in ? (unsigned)pixoff * 32u + (unsigned)(g >> 1) * plane_bytes + (unsigned)(g & 1) * 16u : OOB;
-    out_off[t] = x_live ? (unsigned)(4 * g) * chan_bytes + 8u * x : OOB;  // channel 4 g; + i channels: a scalar offset per store
+    // channel 4 g (+ i channels: a scalar offset per store); a channel slot past C - the last k-group's - is out of range as
+    // well: the scalar part of an address is not range-checked, the lane's is
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out_off[t][i] = (x_live && 4 * g + i < a.C) ? (unsigned)(4 * g) * chan_bytes + 8u * x : OOB;
   }
+  const float clamp_lo = a.clamp01 ? 0.f : -__builtin_inff(), clamp_hi = a.clamp01 ? 1.f : __builtin_inff();
   const unsigned row_bytes = (unsigned)a.W * 32u;
   auto load_row = [&](half8 (&dst)[2][R16_PAIRS], int y) __attribute__((always_inline)) {
     const unsigned yoff = (unsigned)y * row_bytes, oob = (unsigned)y < (unsigned)a.H ? 0u : OOB;
@@ -134,28 +147,36 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
   auto step = [&](auto jc, int y) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;  // (y - y0) mod RING: row y - 1 in slot j, y in j + 1, y + 1 in j + 2
     // The two output-row parities one after the other (py = 0: 60 fragments, dy = -1 included; py = 1: 40): both sets of
-    // accumulators beside the three rows do not fit the register file.  Row y - 1 is done after py = 0's first 20 fragments.
+    // accumulators beside the three rows do not fit the register file.  Within a parity (r16_pass_frag): dy = -1 of every
+    // tile first (row y - 1 is done after 20 fragments and its slot reloaded), then the tiles whose values travel - kx = 0,
+    // 1, 4 -, then the hand-over (edge columns to LDS, barrier, the neighbours' columns back, the DPP moves), and kx = 2, 3
+    // are multiplied WHILE it runs: in round 5's first form the hand-over followed the last MFMA, all eight waves did it
+    // at the same time, and the matrix pipes idled through it (0.52 of the HBM roof; in-kernel ablations: DESIGN 5).
     static_for<2>([&](auto pyc) {
       constexpr int py = decltype(pyc)::value;
-      constexpr int NF = py == 0 ? 60 : 40;
-      __builtin_amdgcn_sched_barrier(0);  // (and a parity's epilogue is not interleaved with the next multiplications)
+      constexpr int NF = py == 0 ? 60 : 40, SYNC_AT = NF - 16;
+      __builtin_amdgcn_sched_barrier(0);  // (a parity's stores are not interleaved with the next parity's multiplications)
       f32x4 acc[5][2];
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[kx][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // each A fragment is multiplied into both pixel tiles; read from LDS two fragments ahead of its use
-      half8 a_cur = s_w[r16_pass_frag(py, 0) * 64 + lane], a_nxt = s_w[r16_pass_frag(py, 1) * 64 + lane];
+      float *slot = edge_mine + py * R16_EDGE_SLOT;
+      const float *right = slot + (R16_EDGE_L + R16_EDGE_R), *left = slot - (R16_EDGE_L + R16_EDGE_R);
+      f32x4 e0, e1, e4, r0[2], r1[2], l4[2];  // the neighbours' edge columns; pixel x + 1's kx = 0, 1 and pixel x - 1's kx = 4 per tile
+      // each A fragment is multiplied into both pixel tiles; read from LDS LICOS_ROWS16_AHEAD fragments ahead of its use
+      constexpr int AH = LICOS_ROWS16_AHEAD;
+      half8 a_ring[AH];
+#pragma unroll
+      for (int q = 0; q < AH; ++q) a_ring[q] = s_w[r16_pass_frag(py, q) * 64 + lane];
       static_for<NF>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
         constexpr R16Frag f = r16_frag(r16_pass_frag(py, n));
-        half8 a_nn = a_nxt;
-        if (n + 2 < NF) a_nn = s_w[r16_pass_frag(py, n + 2 < NF ? n + 2 : 0) * 64 + lane];
+        const half8 a_cur = a_ring[n % AH];
+        if (n + AH < NF) a_ring[n % AH] = s_w[r16_pass_frag(py, n + AH < NF ? n + AH : 0) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           acc[f.kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, row[(j + f.d) % RING][t][f.pair], acc[f.kx][t], 0, 0, 0);
-        a_cur = a_nxt;
-        a_nxt = a_nn;
         // (a fence every four fragments: left alone, the scheduler hoists the fragment reads as far as the register file
         // lets it - twenty in flight - and past it, into scratch)
         if (n % 4 == 3) __builtin_amdgcn_sched_barrier(0);
@@ -166,46 +187,53 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
           load_row(row[j], y + RING - 1);
           __builtin_amdgcn_sched_barrier(0);
         }
-      });
-      // the two columns at this wave's edges, for the waves on either side (one slot per parity)
-      float *slot = edge_mine + py * R16_EDGE_SLOT;
-      if (px_l == 0) {
+        if (n == SYNC_AT - 1) {
+          // kx = 0, 1, 4 are complete: the two columns at this wave's edges, for the waves on either side (one slot per parity)
+          __builtin_amdgcn_sched_barrier(0);
+          if (px_l == 0) {
 #pragma unroll
-        for (int kx = 0; kx < 2; ++kx) *reinterpret_cast<f32x4 *>(slot + kx * 16) = acc[kx][0];
-      }
-      if (px_l == 15) *reinterpret_cast<f32x4 *>(slot + R16_EDGE_L) = acc[4][1];
-      // (not __syncthreads(): its fence may drain vmcnt, and the next rows' loads must stay in flight across the barrier)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const float *right = slot + (R16_EDGE_L + R16_EDGE_R), *left = slot - (R16_EDGE_L + R16_EDGE_R);
+            for (int kx = 0; kx < 2; ++kx) *reinterpret_cast<f32x4 *>(slot + kx * 16) = acc[kx][0];
+          }
+          if (px_l == 15) *reinterpret_cast<f32x4 *>(slot + R16_EDGE_L) = acc[4][1];
+          // (not __syncthreads(): its fence may drain vmcnt, and the next rows' loads must stay in flight across the barrier)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if LICOS_ABL_R16 != 1  // (ablation builds, wrong results: 1 no barrier, 2 no stores)
+          __builtin_amdgcn_s_barrier();
+#endif
+          asm volatile("" ::: "memory");
+          e0 = *reinterpret_cast<const f32x4 *>(right);
+          e1 = *reinterpret_cast<const f32x4 *>(right + 16);
+          e4 = *reinterpret_cast<const f32x4 *>(left + R16_EDGE_L);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the neighbour pixels' values, a channel slot per four fragments of kx = 2, 3: the neighbour lane, the tile's last
+        // lane from the other tile (rotated into place first) or from the neighbour wave
+        if (n >= SYNC_AT && (n - SYNC_AT) % 4 == 1) {
+          constexpr int i = (n - SYNC_AT) / 4;
+          r0[0][i] = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[0][1][i]), acc[0][0][i]);
+          r1[0][i] = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[1][1][i]), acc[1][0][i]);
+          r0[1][i] = dpp_keep<DPP_ROW_SHL1>(e0[i], acc[0][1][i]);
+          r1[1][i] = dpp_keep<DPP_ROW_SHL1>(e1[i], acc[1][1][i]);
+          l4[1][i] = dpp_keep<DPP_ROW_SHR1>(dpp_keep<DPP_ROW_ROR1>(0.f, acc[4][0][i]), acc[4][1][i]);
+          l4[0][i] = dpp_keep<DPP_ROW_SHR1>(e4[i], acc[4][0][i]);
+        }
+      });
       const f32x4 bias_c = *reinterpret_cast<const f32x4 *>(s_bias + 4 * g);
-      const f32x4 e0 = *reinterpret_cast<const f32x4 *>(right), e1 = *reinterpret_cast<const f32x4 *>(right + 16);
-      const f32x4 e4 = *reinterpret_cast<const f32x4 *>(left + R16_EDGE_L);
       const unsigned row_off = (unsigned)(2 * y + py) * Wo * 4u;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        // pixel x + 1's kx = 0, 1 and pixel x - 1's kx = 4, per tile: the neighbour lane, the tile's last lane from the other
-        // tile (rotated into place first) or from the neighbour wave
-        const float r0_t0 = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[0][1][i]), acc[0][0][i]);
-        const float r1_t0 = dpp_keep<DPP_ROW_SHL1>(dpp_keep<DPP_ROW_ROR15>(0.f, acc[1][1][i]), acc[1][0][i]);
-        const float r0_t1 = dpp_keep<DPP_ROW_SHL1>(e0[i], acc[0][1][i]);
-        const float r1_t1 = dpp_keep<DPP_ROW_SHL1>(e1[i], acc[1][1][i]);
-        const float l4_t1 = dpp_keep<DPP_ROW_SHR1>(dpp_keep<DPP_ROW_ROR1>(0.f, acc[4][0][i]), acc[4][1][i]);
-        const float l4_t0 = dpp_keep<DPP_ROW_SHR1>(e4[i], acc[4][0][i]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          float o0 = (acc[2][t][i] + (t ? r0_t1 : r0_t0)) + (t ? l4_t1 : l4_t0) + bias_c[i];
-          float o1 = (acc[3][t][i] + (t ? r1_t1 : r1_t0)) + bias_c[i];
-          if (a.clamp01) {
-            o0 = fminf(fmaxf(o0, 0.f), 1.f);
-            o1 = fminf(fmaxf(o1, 0.f), 1.f);
-          }
+          float o0 = (acc[2][t][i] + r0[t][i]) + l4[t][i] + bias_c[i];
+          float o1 = (acc[3][t][i] + r1[t][i]) + bias_c[i];
+          o0 = __builtin_amdgcn_fmed3f(o0, clamp_lo, clamp_hi);  // (one instruction, no branch on the flag)
+          o1 = __builtin_amdgcn_fmed3f(o1, clamp_lo, clamp_hi);
           typedef float f32x2 __attribute__((ext_vector_type(2)));
-          // (a channel slot past C - the last k-group's - stores past num_records as well: the scalar part of an address is
-          // not range-checked, the lane's is)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, f32x2{o0, o1}), orsrc, 4 * g + i < a.C ? out_off[t] : OOB,
-                                                row_off + i * chan_bytes, 0);
+#if LICOS_ABL_R16 == 2
+          if (o0 == 12345.f)
+#endif
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, f32x2{o0, o1}), orsrc, out_off[t][i], row_off + i * chan_bytes,
+                                                LICOS_ROWS16_STORE_AUX);
         }
       }
     });
@@ -261,13 +289,15 @@ int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, 
   LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_rows_f16: x-split input needs an even width");
   LICOS_REQUIRE((long)Cout * 4 * H * W * 4 < (1L << 31), "deconv5x5s2_rows_f16: an image's output must stay below 2 GB (buffer offsets)");
   a.tiles_x = W <= R16_COLS ? 1 : cdiv(W, R16_COLS - 2);
-  // row blocks: 32 rows when that still fills the chip (input read (32 + 2) / 32 times), 8 rows for small calls
-  a.rows_per_wg = (long)B * a.tiles_x * cdiv(H, LICOS_ROWS16_RH) >= 1024 ? LICOS_ROWS16_RH : 8;
+  // row blocks: 64 rows when that still fills the chip four times over (input read (64 + 2) / 64 times), 32, 8 for small calls
+  // (a tile's bits do not depend on the choice: tests/test_gpu_fp16.py)
+  a.rows_per_wg = (long)B * a.tiles_x * cdiv(H, 2 * LICOS_ROWS16_RH) >= 1024 ? 2 * LICOS_ROWS16_RH
+                  : (long)B * a.tiles_x * cdiv(H, LICOS_ROWS16_RH) >= 1024 ? LICOS_ROWS16_RH : 8;
   a.tiles_y = cdiv(H, a.rows_per_wg);
-  auto kern = deconv5x5s2_rows16_kernel<3>;
-  LICOS_ENSURE_LDS(kern, R16_LDS);
   const long blocks = (long)a.tiles_x * a.tiles_y * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_rows_f16: grid too large");
+  auto kern = deconv5x5s2_rows16_kernel<3>;
+  LICOS_ENSURE_LDS(kern, R16_LDS);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), R16_LDS, s, a);
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;

@@ -52,6 +52,7 @@ SCATTER_LAST = os.environ.get("LICOS_SCATTER", "1") != "0"  # A/B switch for the
 FIRST_ROWS = os.environ.get("LICOS_FIRST", "1") != "0"  # kernel-row first stage (1..3 bands) instead of the space-to-depth 3x3 form
 FIRST_RAW = os.environ.get("LICOS_FIRST_RAW", "1") != "0"  # ... reading the NCHW fp32 image in place (no layout pass) when W % 4 == 0
 ROWS_LAST = os.environ.get("LICOS_ROWS", "1") != "0"  # row-walking last stage (1..3 bands) instead of the scatter form
+ROWS16_LAST = os.environ.get("LICOS_ROWS16_LAST", "1") != "0"  # 5..16 bands: the last stage row-walking (csrc/mfma_rows16.hip), 0 = few16
 FIRST16 = os.environ.get("LICOS_FIRST16", "1") != "0"  # 5..16 bands: the first stage on the NCHW fp32 image in place (csrc/mfma_first16.hip)
 
 
@@ -180,6 +181,14 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
         return (i == len(st) - 1 and isinstance(m, nn.ConvTranspose2d) and g is None and SCATTER_LAST
                 and m.out_channels <= 4 and m.in_channels in (128, 192))
 
+    def rows16_last(i, w):
+        """5..16 bands out of 128 channels: the row-walking form on 16 x 16 x 32 tiles (csrc/mfma_rows16.hip) for maps wide
+        enough to give its eight waves columns (a workgroup spans 256; at 128 columns half of them idle and the LDS-patch
+        form wins: tools/last16_probe.py, 5.4 against 4.2 ms for 2048 maps of 128^2)."""
+        m, g = st[i]
+        return (i == len(st) - 1 and isinstance(m, nn.ConvTranspose2d) and g is None and ROWS_LAST and ROWS16_LAST
+                and 5 <= m.out_channels <= 16 and 112 < m.in_channels <= 128 and w >= 192)
+
     def takes_xsplit(i, h, w):
         """Does stage i, fed an h x w map, read the x-split layout?"""
         if i >= len(st) or w % 2:
@@ -187,7 +196,7 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
         m, g = st[i]
         if not isinstance(m, nn.ConvTranspose2d):
             return False
-        if scatter_last(i):
+        if scatter_last(i) or rows16_last(i, w):
             return True
         return i < len(st) - 1 and bool(ops.deconv_layouts(m.in_channels, h, w, m.out_channels) & ops.EPI_IN_XSPLIT)
 
@@ -196,6 +205,8 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
         if scatter_last(idx):
             fewch = "rows" if (ROWS_LAST and m.out_channels <= 3) else "scatter"
+        elif rows16_last(idx, cur.shape[3]):
+            fewch = "rows"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch, first=(first_rows and idx == 0))
         if fewch in ("rows", "scatter"):
             key = ("deconv", m.in_channels, m.out_channels, cur.shape[2], cur.shape[3], cur.shape[0], False)

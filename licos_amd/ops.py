@@ -1292,7 +1292,7 @@ def pack_deconv_w_rows_f16(w):
     cin, cout = w.shape[:2]
     nbytes = _lib.load().licos_packed_deconv_w_rows_bytes(cin, cout)
     if nbytes == 0:
-        raise ValueError(f"licos_amd: row-walking deconv supports 1..3 output channels, got {cout}")
+        raise ValueError(f"licos_amd: row-walking deconv supports 1..3 output channels (5..16 from 113..128 input channels), got {cin} -> {cout}")
     packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
     _lib.check(_lib.load().licos_pack_deconv_w_rows_f16(_p(_f32(w.contiguous())), cin, cout, _p(packed), _stream()),
                "pack_deconv_w_rows_f16")
@@ -1300,7 +1300,8 @@ def pack_deconv_w_rows_f16(w):
 
 
 def deconv5x5s2_rows_f16(x_blk, w_packed, bias, cin, cout, clamp01=False, out=None, in_xsplit=False):
-    """Last synthesis stage, 1..3 output channels, row-walking form (csrc/mfma_rows.hip): NCHW fp32 out."""
+    """Last synthesis stage, row-walking form: 1..3 output channels (csrc/mfma_rows.hip) or 5..16 out of 113..128
+    (csrc/mfma_rows16.hip): NCHW fp32 out."""
     _dev(x_blk, w_packed, bias, out)
     b, c16, h, w, _ = x_blk.shape
     if c16 != (cin + 15) // 16 or x_blk.dtype != torch.float16:

@@ -251,7 +251,10 @@ def test_scatter_deconv_rejects_unsupported_shapes():
 
 @pytest.mark.parametrize("cin,cout,h,w", [(128, 3, 32, 32), (128, 1, 16, 16), (128, 3, 128, 128), (128, 2, 9, 40), (128, 3, 20, 36),
                                            (192, 3, 8, 33), (192, 1, 5, 3), (128, 3, 1, 1), (128, 3, 7, 130), (128, 1, 4, 300),
-                                           (128, 3, 37, 128)])
+                                           (128, 3, 37, 128),
+                                           # 5..16 bands: csrc/mfma_rows16.hip (256-column strips, two 16-pixel tiles per wave)
+                                           (128, 13, 20, 36), (128, 13, 9, 35), (128, 16, 16, 34), (128, 5, 3, 300), (128, 13, 37, 256),
+                                           (120, 13, 8, 16), (128, 9, 1, 1), (128, 13, 5, 510)])
 def test_rows_deconv_exact_operands(cin, cout, h, w):
     """Row-walking last stage (csrc/mfma_rows.hip): same operands as torch-CPU conv_transpose2d, fp32 sums: ragged widths
     (dead lanes read zeros through the buffer bounds), maps wider than one 128-column strip (126 live columns per strip),
@@ -272,6 +275,11 @@ def test_rows_deconv_exact_operands(cin, cout, h, w):
     assert torch.equal(ops.deconv5x5s2_rows_f16(xb, ws, bd, cin, cout), out)
     if w % 2 == 0:  # the x-split input layout is a pure re-ordering
         assert torch.equal(ops.deconv5x5s2_rows_f16(ops.blk16_xsplit(xb), ws, bd, cin, cout, in_xsplit=True), out)
+    if cout > 4:  # against the LDS-patch form of the same stage (csrc/mfma_deconv.hip)
+        if cin == 128:
+            fw = ops.deconv5x5s2_fewch_f16(xb, ops.pack_deconv_w_fewch_f16(wt.to(DEV)), ops.pad_bias(b, cout, DEV), cin, cout)
+            assert float((fw - out).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        return
     # against the scatter form (2^-20 fixed-point sums of the same products)
     sc = ops.deconv5x5s2_scatter_f16(xb, ops.pack_deconv_w_scatter_f16(wt.to(DEV)), bd, cin, cout)
     assert float((sc - out).abs().max()) < 9 * 2.0 ** -21 + 2e-5 * float(ref.abs().max())
@@ -289,6 +297,22 @@ def test_rows_deconv_is_batch_and_block_invariant():
     one = ops.deconv5x5s2_rows_f16(xb[:1].contiguous(), ws, b, 128, 3)
     big = ops.deconv5x5s2_rows_f16(xb.repeat(64, 1, 1, 1, 1), ws, b, 128, 3)  # ... 2560 x 2 >= 2048 -> 32-row blocks
     assert torch.equal(big[:1], one) and torch.equal(big[40:41], one)
+
+
+def test_rows16_deconv_is_batch_and_block_invariant():
+    """The same for the 13-band form: 8-row blocks for small calls, 32-row blocks for large ones, identical bits."""
+    g = torch.Generator().manual_seed(6)
+    x = h16(torch.randn(10, 128, 64, 64, generator=g))
+    wt = h16(torch.randn(128, 13, 5, 5, generator=g) * 0.05)
+    b = torch.randn(13, generator=g).to(DEV)
+    ws = ops.pack_deconv_w_rows_f16(wt.to(DEV))
+    xb = ops.nchw_f32_to_blk16(x.to(DEV))
+    one = ops.deconv5x5s2_rows_f16(xb[:1].contiguous(), ws, b, 128, 13)
+    big = ops.deconv5x5s2_rows_f16(xb.repeat(60, 1, 1, 1, 1), ws, b, 128, 13)  # 600 x 2 row blocks of 32 >= 1024 -> 32-row blocks
+    assert torch.equal(big[:1], one) and torch.equal(big[10:11], one)
+    del big
+    huge = ops.deconv5x5s2_rows_f16(xb.repeat(110, 1, 1, 1, 1), ws, b, 128, 13)  # 1100 x 1 row block of 64 >= 1024 -> 64-row blocks
+    assert torch.equal(huge[:1], one) and torch.equal(huge[1099:1100], ops.deconv5x5s2_rows_f16(xb[9:10].contiguous(), ws, b, 128, 13))
 
 
 def test_rows_deconv_rejects_unsupported_shapes():

@@ -301,7 +301,10 @@ int licos_rans_decode_host_sym16(const uint8_t *in, const int64_t *byte_off /*[B
 int licos_rans_compact(const uint32_t *words, int cap_words, const int32_t *nwords, const int64_t *byte_off,
                        uint8_t *out, int B, void *stream);
 /* decoder: stream b = in[byte_off[b] .. byte_off[b+1]) ; writes symbols with the
- * same addressing as above; status[0] non-zero if a stream ran past its end. */
+ * same addressing as above; status[0] non-zero if a stream ran past its end.
+ * Round 5: with per-channel tables (no indexes) and stream-major symbols (ssi == 1, ssb and plane multiples of 4,
+ * 16-byte-aligned rows) four symbols leave as one 16-byte store from registers - the fastest form (csrc/rans.hip,
+ * rans_decode_plane4_kernel); licos_eb_dequantize reads that layout with 16-byte loads. */
 int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off /*[B+1]*/, const int32_t *indexes,
                             long sym_stride_b, long sym_stride_i, int n, int plane, const int32_t *cdf,
                             int cdf_stride, const int32_t *cdf_len, const int32_t *offset, int32_t *symbols,
@@ -459,7 +462,12 @@ int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scat
  * Z[(py, kx, c)][y][x] = sum over (dy, cin) as ONE 32-row MFMA tile per 32 input pixels, B operands = the fragments of input
  * rows y-1, y, y+1 held in registers while a wave walks down its 32-column strip (every input row is read once per
  * row block), the x shift out[.., 2x + px] = sum_kx Z[..kx..][x + (px + 2 - kx) / 2] through LDS between neighbouring lanes.
- * fp32 sums in a fixed order.  CompressAI FactorizedPrior.g_s[6] as licos/model_utils.py:38-45 re-sizes it (3 / 1 bands). */
+ * fp32 sums in a fixed order.  CompressAI FactorizedPrior.g_s[6] as licos/model_utils.py:38-45 re-sizes it (3 / 1 bands).
+ * Round 5: also 5..16 output channels out of 113..128 input channels (the 13 merged Sentinel-2 bands of
+ * licos/raw_image_folder.py:168-174; csrc/mfma_rows16.hip): ten 16-row tiles (py, kx) on v_mfma_f32_16x16x32_f16, a wave
+ * walks 32 columns, the x shift by DPP between neighbouring lanes and through LDS only at a wave's edges; same three
+ * entry points, same argument meaning (`licos_packed_deconv_w_rows_bytes` returns 0 for a pair it does not serve).  Built for
+ * maps wide enough to give eight waves columns; below ~192 columns licos_deconv5x5s2_fewch_f16 is faster. */
 size_t licos_packed_deconv_w_rows_bytes(int Cin, int Cout);
 int licos_pack_deconv_w_rows_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_deconv5x5s2_rows_f16(const void *x_blk16, const void *w_packed_rows, const float *bias, float *y_nchw,

@@ -205,7 +205,7 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
         fewch = last and isinstance(m, nn.ConvTranspose2d) and g is None and m.out_channels <= 32
         if scatter_last(idx):
             fewch = "rows" if (ROWS_LAST and m.out_channels <= 3) else "scatter"
-        elif rows16_last(idx, cur.shape[3]):
+        elif last and cur.dim() == 5 and rows16_last(idx, cur.shape[3]):
             fewch = "rows"
         wp, bp = _packed_conv(m, s2d=(s2d_first and idx == 0), fewch=fewch, first=(first_rows and idx == 0))
         if fewch in ("rows", "scatter"):

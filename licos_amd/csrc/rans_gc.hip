@@ -200,17 +200,7 @@ struct WordSink {
   const uint32_t *base;  // row 0 of this stream (wave-uniform part folded in by the compiler or not - a 64-bit pair either way)
   uint32_t off;          // byte offset of the next free row; 0 = the dump row
   uint32_t stride;       // bytes between two rows
-#ifdef LICOS_GC_DEBUG
-  uint32_t limit = 0xFFFFFFFFu;
-  int32_t *dbg = nullptr;
-#endif
   __device__ inline void store(uint32_t w) const {
-#ifdef LICOS_GC_DEBUG
-    if (off >= limit) {
-      if (dbg) atomicOr(dbg, 4);
-      return;
-    }
-#endif
     // (the base through an s_mov: an SGPR the allocator brings back from a VGPR lane with v_readlane must not be read by a
     // vector-memory instruction within five wait states, and nothing inside an asm statement is padded)
     uint64_t base_copy;
@@ -310,10 +300,6 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(co
     if constexpr (COUNTED) { LICOS_REC_LANDED_SLOT("s_waitcnt vmcnt(48)") } else { LICOS_REC_LANDED_SLOT("s_waitcnt vmcnt(0)") }
   };
   WordSink sink{words, ((uint32_t)cap_words * (uint32_t)B + (uint32_t)b) * 4u, (uint32_t)B * 4u};
-#ifdef LICOS_GC_DEBUG
-  sink.limit = ((uint32_t)cap_words + 1u) * (uint32_t)B * 4u;
-  sink.dbg = status;
-#endif
   uint64_t x = RANS_L;
   auto code_symbol = [&](const u32x4 r) {
     const uint32_t cfreq = r.w & 0xFFFFu;  // 2^16 - freq
@@ -326,12 +312,6 @@ __global__ __launch_bounds__(64 * WAVES) void rans_encode_records_regs_kernel(co
     x = x + r.z + q * (uint64_t)cfreq;
   };
   auto code_escape = [&](long i) {
-#ifdef LICOS_GC_DEBUG
-    if (i < 0 || i >= n) {
-      atomicOr(status, 8);
-      return;
-    }
-#endif
     const uint32_t raw = (uint32_t)ap[(size_t)i * B];
     int nbyp = 0;
     while (nbyp < 8 && (raw >> (nbyp * 4)) != 0) ++nbyp;
@@ -624,6 +604,9 @@ __device__ __forceinline__ uint32_t get_bits4(uint64_t &x, RingSource &src) {
   return val;
 }
 
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2_t lds_cu32x2;
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uint8_t *__restrict__ in,
                                                                        const int64_t *__restrict__ byte_off,
@@ -642,6 +625,17 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
   const int wave_b0 = (blockIdx.x * WAVES + wave) * 64;
   if (wave_b0 >= B) return;  // (no barrier below) a wave without streams would also break the store count the waits rely on
   const ImageMeta *s_meta = reinterpret_cast<const ImageMeta *>(s_img + off_meta);
+  // absolute LDS addresses for the speculative fast path (the kernel has no static LDS: the dynamic block starts at 0; the
+  // slow path and everything rare keep their pointers)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+  if (lds0 != 0) {  // (never taken)
+    if (tid == 0) atomicOr(status, 4);
+    return;
+  }
+  const uint32_t ring_addr = (uint32_t)wave * (RING * 256) + (uint32_t)lane * 4u;
+  const uint32_t img_addr = (uint32_t)WAVES * (RING * 64 * 4 + IDEPTH * 64 * 16);
+  uint64_t rans_l = RANS_L;
+  asm volatile("" : "+s"(rans_l));  // (opaque: as a literal the 64-bit compare becomes mask + compare-with-zero)
   const uint2 *s_rec = reinterpret_cast<const uint2 *>(s_img + off_rec);
   const uint16_t *s_cdf = reinterpret_cast<const uint16_t *>(s_img + off_cdf);
   const bool live = wave_b0 + lane < B;
@@ -784,21 +778,25 @@ __global__ __launch_bounds__(64 * WAVES) void rans_decode_image_kernel(const uin
         bool missed = false;
 #pragma unroll
         for (int k = k0; k < k0 + LICOS_GC_SPEC; ++k) {
+          // (round 5, by instruction count - a lone wave pays ~7 cycles for each, DESIGN 6.3: table and ring through absolute
+          // LDS addresses - no base to add, the ring's wrap and base in one v_and_or -, the 15 bits above x >> 16's low word
+          // through a full-rate 24-bit multiply-add instead of a second 64-bit one, the compare against an opaque 2^31)
           const uint32_t pack = mm[q & 1][k].x;
           const uint32_t x_lo = (uint32_t)x, x_hi = (uint32_t)(x >> 32);
           const uint32_t cf = x_lo & 0xFFFFu;
-          const uint2 r = *reinterpret_cast<const uint2 *>(s_img + (pack >> IMAGE_PACK_SHIFT) + ((cf >> (pack & 31u)) << 3));
-          const uint32_t w_next = src.peek();
+          const u32x2_t rr = *(lds_cu32x2 *)(uintptr_t)(img_addr + (pack >> IMAGE_PACK_SHIFT) + ((cf >> (pack & 31u)) << 3));
+          const uint2 r = make_uint2(rr.x, rr.y);
+          const uint32_t w_next = *(lds_cu32 *)(uintptr_t)((((uint32_t)src.rd << 8) & (uint32_t)((RING - 1) << 8)) | ring_addr);
           int s;
           uint32_t off, freq;
           bool miss;
           image_pair(r, cf, s, off, freq, miss);
           missed = missed || miss;
           const uint32_t xs_lo = __builtin_amdgcn_alignbit(x_hi, x_lo, 16), xs_hi = x_hi >> 16;
-          uint64_t nx = (uint64_t)freq * xs_lo + off;
-          nx += (uint64_t)(freq * xs_hi) << 32;
-          const bool need = nx < RANS_L;
-          x = need ? ((nx << 32) | w_next) : nx;
+          const uint64_t p = (uint64_t)freq * xs_lo + off;
+          const uint32_t plo = (uint32_t)p, nhi = __umul24(xs_hi, freq & 0xFFFFFFu) + (uint32_t)(p >> 32);  // freq <= 2^16, xs_hi < 2^15
+          const bool need = (((uint64_t)nhi << 32) | plo) < rans_l;
+          x = need ? (((uint64_t)plo << 32) | w_next) : (((uint64_t)nhi << 32) | plo);
           src.rd += need ? 1 : 0;
           v[k] = s + (int32_t)mm[q & 1][k].y;
         }

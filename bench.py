@@ -180,16 +180,26 @@ def stage_entry(key, ms, launches):
         # HBM-side traffic from the PMC passes of the 3-band 256^2 launches (profiles/README.md), scaled to this launch size
         tfile = None
         if few_in and (cin, h, w) == (3, 256, 256):
-            tfile = "r04_pmc_traffic_first.json"
+            tfile = _traffic_file("pmc_traffic_first.json")
         elif few_out and (cout, h, w) == (3, 128, 128):
-            tfile = "r04_pmc_traffic_rows.json"
+            tfile = _traffic_file("pmc_traffic_rows.json")
         elif few_in and (cin, h, w) == (13, 512, 512):
-            tfile = "r04_pmc_traffic_first16.json"
+            tfile = _traffic_file("pmc_traffic_first16.json")
+        elif few_out and (cout, h, w) == (13, 256, 256):
+            tfile = _traffic_file("pmc_traffic_last16.json")
         if tfile and os.path.exists(os.path.join(ROOT, "profiles", tfile)):
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             ent["traffic"] = tj["hbm_bytes_per_launch"] * b / tj["tiles_per_launch"]
             ent["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tfile
     return ent
+
+
+def _traffic_file(name):
+    """The newest round's PMC summary of that kernel under profiles/ (rNN_<name>), or None."""
+    for rnd in ("r05", "r04", "r03"):
+        if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))):
+            return "%s_%s" % (rnd, name)
+    return None
 
 
 def quality_match(net, sd, x8):
@@ -433,9 +443,9 @@ def hyperprior_grid(args, dev):
             res["psnr_db"] = round(licos_amd.metrics.compute_psnr(d["x_hat"], xb), 3)
             stages, dom = {}, None
             tj = None
-            tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic_hyper_deconv.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
+            tname = _traffic_file("pmc_traffic_hyper_deconv.json")
+            if tname:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
             for key, evs in ev.items():
                 ms_all = [e0.elapsed_time(e1) for e0, e1 in evs]
                 ms = sum(ms_all) / len(ms_all)
@@ -451,7 +461,7 @@ def hyperprior_grid(args, dev):
                                    "frac_conv_only": round(stage_flops(*key[:5]) * key[5] / ms / 1e9 / PEAK_F16_TFLOPS, 4),
                                    "avg_launch_ms": round(ms, 4), "tiles_per_launch": key[5], "launches": len(ev[key]),
                                    "traffic": (tj["hbm_bytes_per_launch"] * key[5] / tj["tiles_per_launch"]) if tj else None,
-                                   "traffic_source": "profiles/r04_pmc_traffic_hyper_deconv.json" if tj else None}
+                                   "traffic_source": ("profiles/" + tname) if tj else None}
             nsym = {"y": 192 * 32 * 32, "z": 128 * 8 * 8}
             coders = {}
             for key, evs in cev.items():
@@ -648,9 +658,10 @@ def main():
 
         # `roofline` = the DOMINANT kernel of the step (largest total time among the MFMA stages, full-size launches);
         # the north-star target kernel g_a[2] rides along as `roofline_g_a2`
-        names = {("conv", 128, 128, 128, 128): ("conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)", "r04_pmc_traffic_conv_a3.json"),
+        names = {("conv", 128, 128, 128, 128): ("conv5x5s2_mfma8_kernel<4,GDN> (g_a[2], 128->128 @128^2->64^2)",
+                                               _traffic_file("pmc_traffic_conv_a3.json") or "none"),
                  ("deconv", 128, 128, 64, 64): ("deconv5x5s2_mfma8_kernel<4,IGDN> (g_s[4], 128->128 @64^2->128^2, 4 phases per workgroup)",
-                                               "r04_pmc_traffic_deconv_s4.json")}
+                                               _traffic_file("pmc_traffic_deconv_s4.json") or "none")}
         full = {k: v for k, v in per_stage_ms.items() if k[5] == max(kk[5] for kk in per_stage_ms)}
         dom = max(full, key=lambda k: full[k] * len(events[k]))
         nm = names.get(dom[:5], ("%s_%d_%d_%dx%d" % dom[:5], "none"))

@@ -32,7 +32,7 @@ class CodecConfig:
     prequeue: int = 3              # LICOS_PREQUEUE: host sub-chunks of a large compress queued before the drains
     hyper_share: int = -1          # LICOS_HYPER_SHARE (dev probe): fixed host share of a scale-hyperprior call; -1 = policy
     # nominal coder rates, ns per symbol (device: per lane = per launch; host: per thread)
-    dev_ns: dict = field(default_factory=lambda: {"enc": 105.0, "dec": 115.0})  # (enc: 145 before the stream-major symbol reads of round 5)
+    dev_ns: dict = field(default_factory=lambda: {"enc": 105.0, "dec": 100.0})  # (round 4: 145 / 115 - before the stream-major symbols and the instruction-counted decoder)
     host_ns: dict = field(default_factory=lambda: {"enc": 1.8, "dec": 4.0})       # LICOS_HOST_ENC_NS / LICOS_HOST_DEC_NS
     expect_ns: dict = field(default_factory=lambda: {"enc": 1.8, "dec": 3.0})     # the coder call alone on a quiet host
     hyper_dev_ns: dict = field(default_factory=lambda: {"enc": 119.0, "dec": 117.0})  # (enc: 159 before the register-ring record encoder of round 5)

@@ -967,9 +967,12 @@ using namespace licos;
 // on the bench step: 1 wave 230.7 ms, 2 waves 227.6 ms, 4 waves 228.4 ms (the waves of a workgroup wait for each other
 // at every channel's table: a 4-wave encode launch takes 8.7 instead of 7.9 ms, and the last one of a step is exposed).
 // LICOS_CODER_WAVES (1, 2 or 4) overrides for A/B runs.
-static int coder_waves(int B) {
+// Round 5: the instruction-counted plane decoder prefers FOUR (95 against 102 ns per symbol alone; a 16 384-tile decompress
+// 100.6 -> 99.2 ms, 1024 tiles 10.4 -> 9.6), the stream-major encoder two (98 against 144 ns: its waves meet at every
+// channel's table) - profiles/r05_coder_waves_ab.log.
+static int coder_waves(int B, bool decoder = false) {
   static const int forced = [] { const char *e = getenv("LICOS_CODER_WAVES"); return e ? atoi(e) : 0; }();
-  int w = (forced == 1 || forced == 2 || forced == 4) ? forced : 2;
+  int w = (forced == 1 || forced == 2 || forced == 4) ? forced : decoder ? 4 : 2;
   while (w > 1 && B <= 64 * (w / 2)) w /= 2;  // small batches: no more waves than there are streams for
   return w;
 }
@@ -1039,7 +1042,7 @@ int licos_rans_decode_batch(const uint8_t *in, const int64_t *byte_off, const in
   }
   static const bool dec4 = [] { const char *e = getenv("LICOS_RANS_DEC4"); return !e || atoi(e) != 0; }();  // (A/B: 0 = the round-4 kernel)
   if (dec4 && !indexes && n % plane == 0 && cdf_stride <= 65535) {
-    int w4 = coder_waves(B);
+    int w4 = coder_waves(B, true);
     auto lds4 = [&](int w) { return (size_t)DEC_LUT_BYTES + (size_t)w * (RING + SYM_BUF) * 256 + (size_t)cdf_stride * 4; };
     while (w4 > 1 && lds4(w4) > 156 * 1024) w4 /= 2;
     if (lds4(w4) <= 156 * 1024) {

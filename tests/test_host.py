@@ -417,7 +417,8 @@ def test_host_share_of_a_call(monkeypatch):
     assert cap_e == int(0.85 * 16 * codec.config.dev_ns["enc"] / codec.config.host_ns["enc"]) // 32 * 32 and 0 < cap_d < cap_e and cap_d % 32 == 0
     for b in (1, 16, 64, 384):
         assert codec.host_share(b, "enc") == b and codec.host_share(b, "dec") == b  # the host-only batches of rounds 2 - 3
-    assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(cap_d + 1, "dec") == cap_d  # split: the call's first tiles
+    # split: the call's first tiles (above the host-only batches, whichever limit is the larger)
+    assert codec.host_share(cap_d, "dec") == cap_d and codec.host_share(max(cap_d, 384) + 1, "dec") == cap_d
     edge = int(codec.config.enc_all_host * cap_e)
     assert codec.host_share(cap_e, "enc") == cap_e and codec.host_share(edge, "enc") == edge  # a little over: still all
     assert codec.host_share(edge + 1, "enc") == int(codec.config.enc_tail * cap_e)  # ... then the call's last tiles

@@ -2,6 +2,7 @@
 // 3x3 stride-1 conv with resident weights, several tiles per workgroup): tile geometry, the K step of one cin chunk and
 // the (I)GDN / pack / store epilogue.
 #pragma once
+#include <type_traits>
 #include "mfma_common.hpp"
 
 // LICOS_ABL (dev builds via tools/ab_build.sh, never the product): timing ablations.
@@ -80,6 +81,12 @@ __device__ __forceinline__ void deconv8_chunk(f32x16 (&acc)[MT][NT], const half8
 // waves take turns between K loop and epilogue (mfma_first16.hip, duo form) join the workgroup's barriers there.
 struct EpilogueNoHook {
   __device__ __forceinline__ void operator()(int) const {}
+};
+// A hook type that derives from this stores through a raw buffer (`out`: the image's output, offsets below 2^31): a lane
+// without a pixel asks for an offset past num_records instead of being masked off, so EVERY block issues its two stores
+// whatever the exec mask - a wave that keeps loads in flight across the epilogue can then count them (mfma_first16.hip).
+struct EpilogueBufferStores {
+  __amdgpu_buffer_rsrc_t out;
 };
 template <int MT, int NT, int EPI, class Hook = EpilogueNoHook>
 __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16x8 *s_gamma, const float *s_beta, _Float16 *y_img,
@@ -162,7 +169,12 @@ __device__ __forceinline__ void tile8_epilogue(f32x16 (&acc)[MT][NT], const bf16
           hi[d] = sw[1];
         }
         const int chunk = 2 * it + gp;
-        if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
+        if constexpr (std::is_base_of<EpilogueBufferStores, Hook>::value) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 val = {lo[0], lo[1], hi[0], hi[1]};
+          const unsigned off = (live && chunk < Cout16) ? pix_off[nt] + (unsigned)chunk * chunk_bytes : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(val, hook.out, off, 0, 2 /* nt */);
+        } else if (live && chunk < Cout16 && (LICOS_ABL != 3 || lo[0] == 0x12345678u)) {
           if (LICOS_STORE_SC1) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 val = {lo[0], lo[1], hi[0], hi[1]};

@@ -23,6 +23,13 @@
 #ifndef LICOS_STORE_BITS
 #define LICOS_STORE_BITS "nt"
 #endif
+// (A/B builds) the duo kernel's raw-row staging: 0 = by the K role into the other group's planes; 1 = by the epilogue role
+// into its own (the epilogue's blocks then store through a raw buffer so that the waits can count past them): correct and
+// SLOWER - 9.83 against 9.45 ms per 1024 tiles (profiles/r05_first16_stage_in_epilogue_ab.log): the epilogue role, not the K
+// role, is what a period waits for.
+#ifndef LICOS_F16D_STAGE_E
+#define LICOS_F16D_STAGE_E 0
+#endif
 #include "mfma_deconv8.hpp"
 
 namespace licos {
@@ -46,6 +53,8 @@ __device__ unsigned long long g_first16_stamps[64];
 #else
 #define F16_STAMP(i) do {} while (0)
 #endif
+
+typedef float lds_f32x4_t __attribute__((ext_vector_type(4)));  // (a native vector: HIP's float4 has no address-space-qualified copy)
 
 struct First16Args {
   const float *x;      // NCHW fp32 [B][C][H][W]
@@ -429,8 +438,11 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
   // left to itself the compiler kept sixteen address registers for these reads alive across the loop and spilled them)
   const float *s_bias_lane = s_bias + 4 * h;
   auto acc_init = [&]() {  // accumulators start at the bias: register q of tile mt is channel 32mt + (q&3) + 8(q>>2) + 4h
-    const float *sb = s_bias_lane;
-    asm volatile("" : "+v"(sb));
+    // (opaque as an LDS ADDRESS, not as a generic pointer: through a generic pointer the reads become flat loads, whose wait
+    // is vmcnt(0) + lgkmcnt(0) - a full round trip of the epilogue's stores issued a moment ago, once per tile)
+    unsigned sb_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float *)s_bias_lane;
+    asm volatile("" : "+v"(sb_addr));
+    const __attribute__((address_space(3))) float *sb = (const __attribute__((address_space(3))) float *)(uintptr_t)sb_addr;
 #ifdef LICOS_F16D_ACC_DIRECT
     // every accumulator quad straight from LDS (the second pixel tile from a second copy of the bias, so that the compiler
     // does not share the read and copy 128 registers): 32 ds_read_b128 and no v_mov
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 bv = *reinterpret_cast<const float4 *>(sb + nt * (2 * 32 * MT) + 32 * mt + 8 * g);
+          const lds_f32x4_t bv = *(const __attribute__((address_space(3))) lds_f32x4_t *)(sb + nt * (2 * 32 * MT) + 32 * mt + 8 * g);
           acc[mt][nt][4 * g + 0] = bv.x;
           acc[mt][nt][4 * g + 1] = bv.y;
           acc[mt][nt][4 * g + 2] = bv.z;
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4 *>(sb + 32 * mt + 8 * g);
+        const lds_f32x4_t bv = *(const __attribute__((address_space(3))) lds_f32x4_t *)(sb + 32 * mt + 8 * g);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           acc[mt][nt][4 * g + 0] = bv.x;
@@ -487,7 +499,20 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
   };
   // Group 0: [K E] x rows, idle.  Group 1: idle, [K E] x rows.  Tile p's K role is period p, its epilogue period p + 1; one
   // straight-line loop body per wave (a role switch inside the loop made the allocator spill the accumulators).
+#if LICOS_F16D_STAGE_E
+  if (grp == 1) {  // period 0: this group's first tile into its own planes
+    Raw rw1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      raw_load(rw1, q, 1);
+      raw_store(rw1, q, 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    idle_period();
+  }
+#else
   if (grp == 1) idle_period();
+#endif
   for (int p = grp; p < n_tiles; p += 2) {
     {
       // ---- K role: tile p from this group's planes; tile p + 1 into the other group's ---------------------------------------
@@ -516,7 +541,9 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
       else if (p + 1 < n_tiles) dma_w(0, wcur ^ 1);
       asm volatile("" ::: "memory");  // the round's loads stay behind the weight request (the counted wait below)
       if (si == 0) F16_STAMP(11);
+#if !LICOS_F16D_STAGE_E
       if (si == 0 || si == 2 || si == 4) raw_load(rw, si >> 1, p + 1);
+#endif
       if (si == 0) F16_STAMP(12);
       {
         constexpr int NI = 5 * MT;
@@ -550,11 +577,13 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
         });
       }
       F16_STAMP(si);
+#if !LICOS_F16D_STAGE_E
       if (si == 1 || si == 3 || si == 4) raw_store(rw, si == 4 ? 2 : si >> 1, grp ^ 1);
+#endif
       F16_STAMP(5);
       // the weight request of this step has landed; a round requested at this step's top (steps 0 and 2) stays in flight:
       // its loads are the wave's youngest operations - 8, or C - 8 for a wave of the second band half
-      if (si == 0 || si == 2) {
+      if (!LICOS_F16D_STAGE_E && (si == 0 || si == 2)) {
         const int half = __builtin_amdgcn_readfirstlane((j_src[si >> 1] >> 16) & 1);
         const int nl = half ? n_hi : 8;
         if (nl == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -580,6 +609,34 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
       if (LICOS_F16D_PRIO_YOUNG && grp == 1) __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E + LICOS_F16D_PRIO_YOUNG);
       else __builtin_amdgcn_s_setprio(LICOS_F16D_PRIO_E);
 #endif
+#if LICOS_F16D_STAGE_E
+      // The epilogue role stages the group's OWN next tile (p + 2) into its own planes, which nobody reads this period: a
+      // round's eight (C - 8) loads are requested behind one barrier and converted two epilogue blocks later.  The blocks
+      // store through a raw buffer - every block issues its two stores whatever the exec mask - so the compiler can count
+      // past them to the round's loads instead of waiting for the stores it has just issued.
+      Raw rws;
+      raw_load(rws, 0, p + 2);
+      struct JoinStage : EpilogueBufferStores {
+        decltype(raw_load) &ld;
+        decltype(raw_store) &st;
+        Raw &rw;
+        int &wcur;
+        int p, grp;
+        __device__ __forceinline__ void operator()(int blk) const {
+          if (blk == 1 || blk == 3 || blk == 5) {
+            st(rw, blk >> 1, grp);
+            if (blk < 5) ld(rw, (blk >> 1) + 1, p + 2);
+          }
+          if (blk == 1 || blk == 3 || blk == 5 || blk == 6) {
+            if (blk == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged planes are complete behind the period's last barrier
+            __builtin_amdgcn_s_barrier();
+            wcur ^= 1;
+          }
+        }
+      };
+      const unsigned out_bytes = (unsigned)Cout16 * a.Ho * a.Wo * 32u;
+      JoinStage join{{__builtin_amdgcn_make_buffer_rsrc(y_img, 0, (int)out_bytes, 0x00020000)}, raw_load, raw_store, rws, wcur, p, grp};
+#else
       auto join = [&](int blk) {
         if (blk == 1 || blk == 3 || blk == 5 || blk == 6) {
           F16_STAMP(8);
@@ -588,6 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv5x5s2_first16_duo_kernel(First16Ar
           wcur ^= 1;
         }
       };
+#endif
       const int oy0 = (yr * run + (p >> 1)) * G::TH, ox0 = (2 * cp + (p & 1)) * G::TW;
       long pix[NT];
 #pragma unroll

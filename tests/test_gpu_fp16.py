@@ -2,6 +2,8 @@
 SAME fp16-rounded operands (so only accumulation order and the output rounding differ), the fused
 (I)GDN epilogue against the fp32 definition, and the whole model against the oracle on the
 quantities BASELINE.json names for the fp16 configuration: bpp, PSNR, symbol mismatch rate."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -982,3 +984,44 @@ def test_fused_quantiser_and_stream_major_symbols_change_no_byte(monkeypatch):
             out[(fused, chunk)] = [bytes(s) for s in c["strings"][0]]
     assert out[(True, 7)] == out[(False, 7)] == out[(True, 16)] == out[(False, 16)]
     assert len(set(out[(True, 7)])) > 1 and min(len(s) for s in out[(True, 7)]) > 8
+
+
+def test_stream_major_coders_agree_with_position_major_ones_at_scale():
+    """The prefetching plane encoder and the instruction-counted plane decoder (round 5) on 2048 streams of real latents, three
+    times over: words and symbols equal to the [position][stream] forms' every time.  (The first form of the encoder's
+    prefetch ring coded a wave's streams from stale registers once in a dozen launches of this size - and never in the small
+    batches of the other tests: loads are slower when the whole chip is asking.)"""
+    from licos_amd import checkpoint, synthetic
+    net = licos_amd.get_model("bmshj2018-factorized", False, 3, 3).to(DEV).eval().set_precision("fp16")
+    wf = os.path.join(os.path.dirname(licos_amd.__file__), "weights", "factorized_q3_c3.pth.tar")
+    if os.path.exists(wf):
+        checkpoint.load_checkpoint(wf, net)
+    else:
+        with torch.no_grad():
+            synthetic.make_trained_like(net, seed=3)
+    net.update(force=True)
+    eb = net.entropy_bottleneck
+    cdf, cdf_len, offset, table = eb.coder_tables()
+    B, plane = 2048, 256
+    nsym = cdf.shape[0] * plane
+    x = synthetic.tiles(B, 3, 256, seed=9, device=DEV)
+    with torch.no_grad():
+        sy = engine.run_chain_fp16(net.g_a, x=x, symbols=(eb.medians_vec(), None))
+    sym_sm = sy.reshape(B, nsym).contiguous()
+    sym_pm = sym_sm.t().contiguous()
+    del x, sy
+    cap = nsym // 2 + 64
+    w0, n0, s0 = ops.rans_encode_batch(sym_pm, 1, B, nsym, plane, cdf, cdf_len, offset, table, cap, B)
+    assert int(s0) == 0
+    byte_off = torch.zeros(B + 1, device=DEV, dtype=torch.int64)
+    byte_off[1:] = torch.cumsum(n0.to(torch.int64) * 4, 0)
+    data = ops.rans_compact(w0, n0, byte_off, int(byte_off[-1]))
+    mx = int(n0.max())
+    for _ in range(3):
+        w1, n1, s1 = ops.rans_encode_batch(sym_sm, nsym, 1, nsym, plane, cdf, cdf_len, offset, table, cap, B)
+        assert int(s1) == 0 and torch.equal(n0, n1)
+        assert torch.equal(torch.where(torch.arange(cap, device=DEV)[:, None] >= cap - n0[None, :], w0, 0)[cap - mx:],
+                           torch.where(torch.arange(cap, device=DEV)[:, None] >= cap - n1[None, :], w1, 0)[cap - mx:])
+        out = torch.empty((B, nsym), device=DEV, dtype=torch.int32)
+        st = ops.rans_decode_batch(data, byte_off, nsym, 1, nsym, plane, cdf, cdf_len, offset, out, B, off_offset=0)
+        assert int(st) == 0 and torch.equal(out, sym_sm)

@@ -22,8 +22,9 @@
 // bit-reproducible, and a tile's result does not depend on the batch or on the row-block size.
 #include "mfma_common.hpp"
 
-// A/B builds only (tools/ab_build.sh): rows per workgroup for large calls, cache-policy bits of the output stores (raw
-// buffer aux: 1 sc0, 2 nt, 16 sc1)
+// A/B builds only (tools/ab_build.sh): rows per workgroup for large calls (the launcher doubles it when the grid stays
+// large), A fragments read ahead of their MFMAs, timing ablations (1 no barrier, 2 no stores: wrong results), cache-policy
+// bits of the output stores (raw buffer aux: 1 sc0, 2 nt, 16 sc1)
 #ifndef LICOS_ROWS16_RH
 #define LICOS_ROWS16_RH 32
 #endif

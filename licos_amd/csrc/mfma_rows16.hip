@@ -12,7 +12,8 @@
 // vmcnt(0) + two barriers per chunk pair: 0.46 - 0.47 of the HBM roof in the config-5 bench).  Here a wave owns 32 columns
 // (two 16-pixel B tiles) and walks DOWN its strip with three input rows in registers (each row is loaded once and used by
 // three consecutive steps; the next row is requested as soon as row y - 1 has been multiplied), eight waves side by side
-// cover 256 columns - a whole row of the 256-wide maps of config 5.
+// cover 256 columns - a whole row of the 256-wide maps of config 5 - or, for maps up to 128 wide, four side by side in two
+// row groups.
 //
 // The x shift: a D tile holds channel 4 g + i of pixel lane % 16, so the neighbour pixel is the neighbour LANE - two DPP
 // moves per value (row_shl / row_shr within the 16 lanes of a k-group, the lane at the tile's end filled from the other
@@ -51,10 +52,14 @@ struct Rows16Args {
   int B, H, W, C, tiles_x, tiles_y, rows_per_wg, clamp01, in_xsplit;
 };
 
-constexpr int R16_WAVES = 8, R16_COLS = 32 * R16_WAVES, R16_NFRAG = 100, R16_CC = 8, R16_PAIRS = R16_CC / 2;
+// Eight waves per workgroup, as CW side by side (32 columns each) x 8 / CW row groups (each walks its own share of the
+// workgroup's rows with its own ring; all eight meet at the same barriers): CW = 8 for maps wider than 128 columns, CW = 4
+// below - eight columns of waves over a 128-wide map leave half of them without pixels (5.4 against few16's 4.2 ms for 2048
+// maps of 128^2).
+constexpr int R16_WAVES = 8, R16_NFRAG = 100, R16_CC = 8, R16_PAIRS = R16_CC / 2;
 constexpr int R16_EDGE_L = 2 * 16, R16_EDGE_R = 16;                               // floats a wave hands left (kx 0, 1) / right (kx 4), per parity
-constexpr int R16_EDGE_SLOT = (R16_WAVES + 2) * (R16_EDGE_L + R16_EDGE_R);        // (a never-written zero entry on either side)
-constexpr int R16_LDS = R16_NFRAG * 64 * 16 + 2 * R16_EDGE_SLOT * 4 + 16 * 4;
+constexpr int r16_edge_slot(int cw) { return (R16_WAVES / cw) * (cw + 2) * (R16_EDGE_L + R16_EDGE_R); }  // (per row group a never-written zero entry on either side)
+constexpr int r16_lds(int cw) { return R16_NFRAG * 64 * 16 + 2 * r16_edge_slot(cw) * 4 + 16 * 4; }
 
 // fragment `it` of a row's 100: d = dy + 1 outermost, then the chunk pair, then the tile (py, kx) - d = 0 has the py = 0 tiles only
 struct R16Frag { int d, pair, py, kx; };
@@ -79,8 +84,9 @@ __device__ __forceinline__ float dpp_keep(float old, float src) {  // lanes whos
 }
 constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR15 = 0x12F;
 
-template <int RING>
+template <int RING, int CW>
 __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows16Args a) {
+  constexpr int RG = R16_WAVES / CW, R16_COLS = 32 * CW, R16_EDGE_SLOT = r16_edge_slot(CW);
   static_assert(RING == 3, "rows y - 1, y, y + 1; the slot of y - 1 takes row y + 2 once it has been multiplied");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   half8 *s_w = reinterpret_cast<half8 *>(smem);                                    // [100][64]
@@ -88,11 +94,15 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
   float *s_bias = s_edge + 2 * R16_EDGE_SLOT;                                      // [16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave / CW, cwv = wave % CW;  // row group, column wave
   const int px_l = lane & 15, g = lane >> 4;
   int b, tile;
   xcd_work_item(blockIdx.x, a.B, a.tiles_x * a.tiles_y, b, tile);
   const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-  const int y0 = tyi * a.rows_per_wg, y1 = min(y0 + a.rows_per_wg, a.H);
+  // this row group's rows: every group takes rows_per_wg / RG STEPS (the barriers are the workgroup's), rows past the map
+  // read zeros and store nowhere
+  const int rpg = a.rows_per_wg / RG;
+  const int y0 = tyi * a.rows_per_wg + rg * rpg, y1 = RG == 1 ? min(y0 + rpg, a.H) : y0 + rpg;
   // one strip covers maps up to 256 wide; wider maps: strips of 254 live columns with one shared column on either side
   const int xorg = a.tiles_x == 1 ? 0 : (R16_COLS - 2) * txi - 1;
 
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
   const unsigned chan_bytes = (unsigned)Ho * Wo * 4u;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int col = 32 * wave + 16 * t + px_l, x = xorg + col;
+    const int col = 32 * cwv + 16 * t + px_l, x = xorg + col;
     const bool x_in = x >= 0 && x < a.W;
     const bool x_live = x_in && (a.tiles_x == 1 || (col >= 1 && col <= R16_COLS - 2));
     const int pixoff = a.in_xsplit ? (x & 1) * (a.W >> 1) + (x >> 1) : x;
@@ -137,8 +147,9 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
   };
 
   if (tid < 16) s_bias[tid] = tid < a.C ? a.bias[tid] : 0.f;
-  // this wave's edge values live in entry wave + 1 of a slot; the neighbours' are entries wave + 2 (right) and wave (left)
-  float *edge_mine = s_edge + (wave + 1) * (R16_EDGE_L + R16_EDGE_R) + 4 * g;
+  // this wave's edge values live in entry cwv + 1 of its row group's part of a slot; the neighbours' are the entries on
+  // either side
+  float *edge_mine = s_edge + (rg * (CW + 2) + cwv + 1) * (R16_EDGE_L + R16_EDGE_R) + 4 * g;
 
   half8 row[RING][2][R16_PAIRS];
 #pragma unroll
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
       });
       const f32x4 bias_c = *reinterpret_cast<const f32x4 *>(s_bias + 4 * g);
       const unsigned row_off = (unsigned)(2 * y + py) * Wo * 4u;
+      const bool row_ok = RG == 1 || y < a.H;  // (uniform; with one row group the loop ends at the map's last row)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -233,8 +245,8 @@ __global__ __launch_bounds__(64 * R16_WAVES) void deconv5x5s2_rows16_kernel(Rows
 #if LICOS_ABL_R16 == 2
           if (o0 == 12345.f)
 #endif
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, f32x2{o0, o1}), orsrc, out_off[t][i], row_off + i * chan_bytes,
-                                                LICOS_ROWS16_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, f32x2{o0, o1}), orsrc, row_ok ? out_off[t][i] : OOB,
+                                                row_ok ? row_off + i * chan_bytes : 0u, LICOS_ROWS16_STORE_AUX);
         }
       }
     });
@@ -289,7 +301,8 @@ int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, 
   a.in_xsplit = (flags >> 1) & 1;
   LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_rows_f16: x-split input needs an even width");
   LICOS_REQUIRE((long)Cout * 4 * H * W * 4 < (1L << 31), "deconv5x5s2_rows_f16: an image's output must stay below 2 GB (buffer offsets)");
-  a.tiles_x = W <= R16_COLS ? 1 : cdiv(W, R16_COLS - 2);
+  const int cw = W <= 128 ? 4 : 8, cols = 32 * cw;
+  a.tiles_x = W <= cols ? 1 : cdiv(W, cols - 2);
   // row blocks: 64 rows when that still fills the chip four times over (input read (64 + 2) / 64 times), 32, 8 for small calls
   // (a tile's bits do not depend on the choice: tests/test_gpu_fp16.py)
   a.rows_per_wg = (long)B * a.tiles_x * cdiv(H, 2 * LICOS_ROWS16_RH) >= 1024 ? 2 * LICOS_ROWS16_RH
@@ -297,9 +310,15 @@ int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, 
   a.tiles_y = cdiv(H, a.rows_per_wg);
   const long blocks = (long)a.tiles_x * a.tiles_y * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_rows_f16: grid too large");
-  auto kern = deconv5x5s2_rows16_kernel<3>;
-  LICOS_ENSURE_LDS(kern, R16_LDS);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), R16_LDS, s, a);
+  if (cw == 4) {
+    auto kern = deconv5x5s2_rows16_kernel<3, 4>;
+    LICOS_ENSURE_LDS(kern, r16_lds(4));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), r16_lds(4), s, a);
+  } else {
+    auto kern = deconv5x5s2_rows16_kernel<3, 8>;
+    LICOS_ENSURE_LDS(kern, r16_lds(8));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), r16_lds(8), s, a);
+  }
   LICOS_LAUNCH_CHECK();
   return LICOS_OK;
 }

@@ -182,12 +182,13 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
                 and m.out_channels <= 4 and m.in_channels in (128, 192))
 
     def rows16_last(i, w):
-        """5..16 bands out of 128 channels: the row-walking form on 16 x 16 x 32 tiles (csrc/mfma_rows16.hip) for maps wide
-        enough to give its eight waves columns (a workgroup spans 256; at 128 columns half of them idle and the LDS-patch
-        form wins: tools/last16_probe.py, 5.4 against 4.2 ms for 2048 maps of 128^2)."""
+        """5..16 bands out of 128 channels: the row-walking form on 16 x 16 x 32 tiles (csrc/mfma_rows16.hip) for maps that
+        give its waves columns: a workgroup is 8 waves x 32 columns for maps wider than 128 and 4 x 32 (two row groups) up to
+        128; where most of a strip's waves would idle the LDS-patch form wins (tools/last16_probe.py: 2048 maps of 128^2 3.6
+        against 4.1 ms, 8192 of 64^2 5.3 against 4.1)."""
         m, g = st[i]
         return (i == len(st) - 1 and isinstance(m, nn.ConvTranspose2d) and g is None and ROWS_LAST and ROWS16_LAST
-                and 5 <= m.out_channels <= 16 and 112 < m.in_channels <= 128 and w >= 192)
+                and 5 <= m.out_channels <= 16 and 112 < m.in_channels <= 128 and (w >= 192 or 96 <= w <= 128))
 
     def takes_xsplit(i, h, w):
         """Does stage i, fed an h x w map, read the x-split layout?"""

@@ -467,8 +467,8 @@ int licos_deconv5x5s2_scatter_f16(const void *x_blk16, const void *w_packed_scat
  * licos/raw_image_folder.py:168-174; csrc/mfma_rows16.hip): ten 16-row tiles (py, kx) on v_mfma_f32_16x16x32_f16, a wave
  * walks 32 columns, the x shift by DPP between neighbouring lanes and through LDS only at a wave's edges; same three
  * entry points, same argument meaning (`licos_packed_deconv_w_rows_bytes` returns 0 for a pair it does not serve).  A workgroup
- * is 8 waves x 32 columns above 128 columns and 4 x 32 in two row groups up to 128; where most of a strip's waves would have
- * no pixels (below ~96 columns, and between 129 and ~191) licos_deconv5x5s2_fewch_f16 is faster. */
+ * is 8 waves x 32 columns above 128 columns, 4 x 32 in two row groups up to 128, 2 x 32 in four up to 64; where most of a
+ * strip's waves would have no pixels (below ~48 columns, 65 - 95, 129 - 191) licos_deconv5x5s2_fewch_f16 is faster. */
 size_t licos_packed_deconv_w_rows_bytes(int Cin, int Cout);
 int licos_pack_deconv_w_rows_f16(const float *w /*[Cin][Cout][5][5]*/, int Cin, int Cout, void *packed, void *stream);
 int licos_deconv5x5s2_rows_f16(const void *x_blk16, const void *w_packed_rows, const float *bias, float *y_nchw,

@@ -54,8 +54,8 @@ struct Rows16Args {
 
 // Eight waves per workgroup, as CW side by side (32 columns each) x 8 / CW row groups (each walks its own share of the
 // workgroup's rows with its own ring; all eight meet at the same barriers): CW = 8 for maps wider than 128 columns, CW = 4
-// below - eight columns of waves over a 128-wide map leave half of them without pixels (5.4 against few16's 4.2 ms for 2048
-// maps of 128^2).
+// up to 128, CW = 2 up to 64 - eight columns of waves over a 128-wide map leave half of them without pixels (5.4 against
+// few16's 4.2 ms for 2048 maps of 128^2; with four columns 3.6).
 constexpr int R16_WAVES = 8, R16_NFRAG = 100, R16_CC = 8, R16_PAIRS = R16_CC / 2;
 constexpr int R16_EDGE_L = 2 * 16, R16_EDGE_R = 16;                               // floats a wave hands left (kx 0, 1) / right (kx 4), per parity
 constexpr int r16_edge_slot(int cw) { return (R16_WAVES / cw) * (cw + 2) * (R16_EDGE_L + R16_EDGE_R); }  // (per row group a never-written zero entry on either side)
@@ -301,7 +301,7 @@ int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, 
   a.in_xsplit = (flags >> 1) & 1;
   LICOS_REQUIRE(!a.in_xsplit || W % 2 == 0, "deconv5x5s2_rows_f16: x-split input needs an even width");
   LICOS_REQUIRE((long)Cout * 4 * H * W * 4 < (1L << 31), "deconv5x5s2_rows_f16: an image's output must stay below 2 GB (buffer offsets)");
-  const int cw = W <= 128 ? 4 : 8, cols = 32 * cw;
+  const int cw = W <= 64 ? 2 : W <= 128 ? 4 : 8, cols = 32 * cw;
   a.tiles_x = W <= cols ? 1 : cdiv(W, cols - 2);
   // row blocks: 64 rows when that still fills the chip four times over (input read (64 + 2) / 64 times), 32, 8 for small calls
   // (a tile's bits do not depend on the choice: tests/test_gpu_fp16.py)
@@ -310,7 +310,11 @@ int rows16_launch(const void *x_blk16, const void *w_packed, const float *bias, 
   a.tiles_y = cdiv(H, a.rows_per_wg);
   const long blocks = (long)a.tiles_x * a.tiles_y * a.B;
   LICOS_REQUIRE(blocks < (1L << 31), "deconv5x5s2_rows_f16: grid too large");
-  if (cw == 4) {
+  if (cw == 2) {
+    auto kern = deconv5x5s2_rows16_kernel<3, 2>;
+    LICOS_ENSURE_LDS(kern, r16_lds(2));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), r16_lds(2), s, a);
+  } else if (cw == 4) {
     auto kern = deconv5x5s2_rows16_kernel<3, 4>;
     LICOS_ENSURE_LDS(kern, r16_lds(4));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * R16_WAVES), r16_lds(4), s, a);

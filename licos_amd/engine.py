@@ -183,12 +183,12 @@ def run_chain_fp16(seq, x=None, x_blk=None, clamp01=False, out=None, symbols=Non
 
     def rows16_last(i, w):
         """5..16 bands out of 128 channels: the row-walking form on 16 x 16 x 32 tiles (csrc/mfma_rows16.hip) for maps that
-        give its waves columns: a workgroup is 8 waves x 32 columns for maps wider than 128 and 4 x 32 (two row groups) up to
-        128; where most of a strip's waves would idle the LDS-patch form wins (tools/last16_probe.py: 2048 maps of 128^2 3.6
-        against 4.1 ms, 8192 of 64^2 5.3 against 4.1)."""
+        give its waves columns: a workgroup is 8 waves x 32 columns for maps wider than 128, 4 x 32 in two row groups up to
+        128, 2 x 32 in four up to 64; where most of a strip's waves would idle the LDS-patch form wins (tools/last16_probe.py:
+        2048 maps of 128^2 3.6 against 4.1 ms, 8192 of 64^2 3.7 against 4.0, 8192 of 32^2 2.5 against 1.1)."""
         m, g = st[i]
         return (i == len(st) - 1 and isinstance(m, nn.ConvTranspose2d) and g is None and ROWS_LAST and ROWS16_LAST
-                and 5 <= m.out_channels <= 16 and 112 < m.in_channels <= 128 and (w >= 192 or 96 <= w <= 128))
+                and 5 <= m.out_channels <= 16 and 112 < m.in_channels <= 128 and (w >= 192 or 96 <= w <= 128 or 48 <= w <= 64))
 
     def takes_xsplit(i, h, w):
         """Does stage i, fed an h x w map, read the x-split layout?"""
